@@ -1,0 +1,104 @@
+/*
+ * vitk: C ABI of the MI355X (gfx950) kernels behind the ViT forward path.
+ *
+ * The reference (ZhiyuanChen/vit) has no FFI or operator plug-in interface: its
+ * forward path is a Python nn.Module that dispatches stock torch ops.  This
+ * library sits UNDER a module with that same Python surface
+ * (vit_amd/vision_transformer.py), one entry point per fused kernel; each
+ * comment names the reference call sites the entry point replaces (paths are
+ * relative to the reference tree).
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer owned by the caller; the library never
+ *    allocates, frees or retains memory.  Tensors are contiguous row-major unless
+ *    a stride argument says otherwise, and 16-byte aligned.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *    Calls only enqueue work; nothing synchronises.
+ *  - Return value: VITK_OK, or an error code; vitk_last_error() then returns a
+ *    message for the calling thread.  No C++ exception crosses this boundary.
+ *  - bf16 tensors are raw 16-bit brain-float words (torch.bfloat16 storage).
+ */
+#ifndef VITK_H_
+#define VITK_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VITK_OK 0
+#define VITK_ERR_INVALID 1      /* null pointer, non-positive size, misaligned pointer */
+#define VITK_ERR_UNSUPPORTED 2  /* a shape or dtype no kernel of this library covers */
+#define VITK_ERR_LAUNCH 3       /* the HIP runtime rejected the launch */
+
+#define VITK_F32 0
+#define VITK_BF16 1
+
+/* ABI version of this header (bumped on any signature change). */
+int vitk_version(void);
+
+/* Message for the last non-zero return on the calling thread ("" if none). */
+const char* vitk_last_error(void);
+
+/* Test hook: choose an alternative implementation of the tiled GEMM
+ * (0 = LDS-DMA staging, 1 = register staging, 2 = force the small untiled kernel)
+ * and of attention (0 = transposed LDS reads of V, 1 = V stored transposed in LDS).
+ * Process-global; results are identical across variants up to fp32 summation order. */
+void vitk_set_debug_variant(int gemm_variant, int attention_variant);
+
+/* y[r, :] = LayerNorm(x[r, :]) * gamma + beta over D columns, fp32 statistics.
+ * x: f32, row r at x + r*x_row_stride; y: bf16 or f32 (out_dtype), row stride y_row_stride
+ * (strides in elements).  D in {256, 512, 768, 1024, 1280}.
+ * Replaces nn.LayerNorm at models/transformer.py:68,73,98 (built :56,60,93). */
+int vitk_layernorm(const float* x, int64_t x_row_stride, const float* gamma, const float* beta, void* y,
+                   int64_t y_row_stride, int rows, int D, float eps, int out_dtype, void* stream);
+
+/* out[i] = bf16(in[i]), n % 8 == 0.  Input images arrive fp32 when the caller has not cast them. */
+int vitk_cast_f32_bf16(const float* in, void* out, int64_t n, void* stream);
+
+/* Patch embedding + cls token + position embedding:
+ *   x[b, 0, :]     = cls + pos[0, :]
+ *   x[b, 1 + p, :] = conv(img)[b, :, p] + bias + pos[1 + p, :]
+ * img: bf16 [batch, 3, img_h, img_w]; w: bf16 [D, 3*patch*patch] (Conv2d weight, OIHW flattened);
+ * bias, cls: f32 [D]; pos: f32 [1 + (img_h/patch)*(img_w/patch), D]; x: f32 [batch, ntok, D].
+ * patch must be a power of two >= 8, img_w % 8 == 0, D % 256 == 0.
+ * Replaces nn.Conv2d + flatten + transpose + cat + add at models/vision_transformer.py:47-50. */
+int vitk_patch_embed(const void* img, const void* w, const float* bias, const float* cls, const float* pos,
+                     float* x, int batch, int img_h, int img_w, int patch, int D, void* stream);
+
+/* out[M,N] = A[M,K] @ W[N,K]^T + bias, A and W bf16, fp32 accumulate; out bf16 or f32 (out_dtype).
+ * bias may be NULL.  K % 32 == 0.  Replaces nn.Linear (models/vision_transformer.py:30,55). */
+int vitk_gemm_bias(const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                   int out_dtype, void* stream);
+
+/* out bf16 [M,N] = gelu_erf(A @ W^T + bias).  Replaces fc1 + nn.GELU at models/transformer.py:21-22. */
+int vitk_gemm_bias_gelu(const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                        void* stream);
+
+/* out bf16 [M,N] = tanh(A @ W^T + bias).  Replaces pre_logits + tanh at models/vision_transformer.py:53-54. */
+int vitk_gemm_bias_tanh(const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                        void* stream);
+
+/* out f32 [M,N] = resid + A @ W^T + bias; out may alias resid (in-place residual update).
+ * Replaces out_proj + residual add (models/transformer.py:47,72) and fc2 + residual add (:24,76). */
+int vitk_gemm_bias_residual(const void* A, const void* W, const float* bias, const float* resid, float* out,
+                            int M, int N, int K, void* stream);
+
+/* Fused q/k/v projection with the head split:
+ *   qkv[which, b, h, t, e] = (A @ W^T + bias)[b*ntok + t, which*D + h*hd + e],  D = heads*hd
+ * A: bf16 [batch*ntok, D]; W: bf16 [3D, D]; bias f32 [3D] or NULL; qkv: bf16 [3, batch, heads, ntok, hd].
+ * Replaces in_proj + reshape + permute at models/transformer.py:42. */
+int vitk_qkv_proj(const void* A, const void* W, const float* bias, void* qkv, int batch, int ntok, int heads,
+                  int hd, void* stream);
+
+/* ctx[b, t, h*hd + e] = sum_s softmax_s(q[b,h,t,:] . k[b,h,s,:] * scale) * v[b,h,s,e]
+ * q, k, v: bf16 [batch, heads, ntok, hd]; ctx: bf16 [batch, ntok, heads*hd].  hd == 64, ntok <= 608.
+ * Replaces q@k^T, scaling, softmax, @v, transpose, reshape at models/transformer.py:43-46. */
+int vitk_attention(const void* q, const void* k, const void* v, void* ctx, int batch, int heads, int ntok,
+                   int hd, float scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITK_H_ */

@@ -1,0 +1,202 @@
+"""Generate the golden vectors under tests/golden/ from the reference itself.
+
+Runs ONLY in the build container, where the reference tree is mounted at
+/root/reference: it imports the reference's `models.vision_transformer` and
+`converter`, feeds them the synthetic tensors of `vit_amd.synth`, and stores
+inputs/outputs as small .npz/.json fixtures.  Nothing here is used at test
+time; the tests read the fixtures.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+from functools import partial
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+sys.path.insert(1, "/root/reference")
+
+from models import vision_transformer as ref_vt          # noqa: E402  (reference)
+import converter as ref_converter                        # noqa: E402  (reference)
+from vit_amd import synth                                 # noqa: E402
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def capture(model):
+    """Run `model` and capture the intermediates the fixtures keep."""
+    st = {}
+    hooks = [
+        model.encoder.blocks[0].register_forward_hook(lambda m, i, o: st.__setitem__("block0", o)),
+        model.encoder.register_forward_hook(lambda m, i, o: st.__setitem__("encoded", o)),
+        model.dropout.register_forward_hook(lambda m, i, o: st.__setitem__("embed", o)),
+        model.encoder.blocks[0].attention.in_proj.register_forward_hook(
+            lambda m, i, o: st.__setitem__("qkv0", o)),
+        model.encoder.blocks[0].attention.out_proj.register_forward_hook(
+            lambda m, i, o: st.__setitem__("ctx0", i[0])),
+    ]
+    return st, hooks
+
+
+def tiny():
+    """A tiny model built and initialised by the reference class itself."""
+    torch.manual_seed(0)
+    kw = dict(img_size=32, patches=8, hidden_size=32, num_layers=2, num_heads=2,
+              num_classes=10, norm=partial(torch.nn.LayerNorm, eps=1e-6))
+    m = ref_vt.VisionTransformer(**kw).eval()
+    # make biases / LN affine non-trivial so they are visible in parity tests
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith(".bias"):
+                p.add_(0.05 * torch.randn(p.shape, generator=g))
+            elif "norm" in n and n.endswith(".weight"):
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+    x = torch.randn(3, 3, 32, 32, generator=g)
+    st, hooks = capture(m)
+    with torch.no_grad():
+        y = m(x)
+    for h in hooks:
+        h.remove()
+    out = {"input": np_(x), "logits": np_(y)}
+    out.update({"stage." + k: np_(v) for k, v in st.items()})
+    out.update({"sd." + k: np_(v) for k, v in m.state_dict().items()})
+    np.savez(os.path.join(HERE, "tiny.npz"), **out)
+    kw.pop("norm")
+    kw["eps"] = 1e-6
+    kw["mlp_ratio"] = 4
+    with open(os.path.join(HERE, "tiny.json"), "w") as f:
+        json.dump(kw, f, indent=1)
+    print("tiny", y.shape, sum(v.size for v in out.values()) * 4 // 1024, "KiB")
+
+
+def full(name, arch, img_size, batch, style, seed=0, pool=24):
+    """Logits of the reference on `batch` images of the synthetic stream.
+
+    Under random-init weights all 1000 logits lie within about +-1 and the
+    top-1/top-2 gap of some images is far below bf16 rounding error, so the
+    parity set is the `batch` images of the first `pool` stream images whose
+    reference margin is largest; their stream indices are stored."""
+    cfg = synth.ARCHS[arch]
+    sd = synth.synth_state_dict(cfg, img_size, seed=seed, style=style)
+    m = getattr(ref_vt, arch)(img_size=img_size).eval()
+    missing = m.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        cand = torch.cat([m(synth.synth_images(4, img_size, seed=seed + 1, first=i))
+                          for i in range(0, pool, 4)])
+    t2 = cand.topk(2, dim=-1).values
+    order = torch.argsort(t2[:, 0] - t2[:, 1], descending=True)[:batch]
+    indices = sorted(int(i) for i in order)
+    x = synth.synth_images(batch, img_size, seed=seed + 1, indices=indices)
+    st, hooks = capture(m)
+    with torch.no_grad():
+        y = m(x)
+    for h in hooks:
+        h.remove()
+    top2 = y.topk(2, dim=-1)
+    out = {
+        "logits": np_(y),
+        "top1": np_(top2.indices[:, 0]).astype(np.int64),
+        "margin": np_(top2.values[:, 0] - top2.values[:, 1]),
+        "embed_slice": np_(st["embed"][:, :5, :32]),
+        "embed_last": np_(st["embed"][:, -1, :]),
+        "qkv0_slice": np_(st["qkv0"][:, :5, ::37]),
+        "ctx0_slice": np_(st["ctx0"][:, :5, ::13]),
+        "block0_slice": np_(st["block0"][:, :5, :32]),
+        "block0_last": np_(st["block0"][:, -1, :]),
+        "encoded": np_(st["encoded"]),
+    }
+    meta = dict(arch=arch, img_size=img_size, batch=batch, style=style, seed=seed,
+                image_seed=seed + 1, image_indices=indices, min_margin=float(out["margin"].min()),
+                n_keys=len(sd), missing=str(missing))
+    np.savez(os.path.join(HERE, name + ".npz"), **out)
+    with open(os.path.join(HERE, name + ".json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print(name, y.shape, "min margin %.3e" % meta["min_margin"], flush=True)
+
+
+def keys():
+    """state_dict key/shape lists as the reference classes produce them."""
+    out = {}
+    for arch, img in (("s16", 224), ("b16", 224), ("b16", 384), ("b32", 224),
+                      ("l16", 224), ("l32", 224), ("h14", 224)):
+        m = getattr(ref_vt, arch)(img_size=img)
+        out[f"{arch}_{img}"] = [[k, list(v.shape), str(v.dtype)] for k, v in m.state_dict().items()]
+    m = ref_vt.VisionTransformer(img_size=32, patches=8, hidden_size=32, num_layers=1,
+                                 num_heads=2, num_classes=7, pre_logits=False)
+    out["nopre_32"] = [[k, list(v.shape), str(v.dtype)] for k, v in m.state_dict().items()]
+    with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
+        json.dump(out, f)
+    print("keys", {k: len(v) for k, v in out.items()})
+
+
+def flax_npz(D=32, H=2, L=2, P=8, n_tok=17, M=128, ncls=10, seed=7):
+    """A Flax-ViT-style checkpoint (the key layout converter.py:11-58 reads)."""
+    hd = D // H
+    z = {}
+
+    def put(k, shape, std=0.05):
+        z[k] = synth.normal(seed, k, shape, std)
+
+    put("cls", (1, 1, D))
+    put("embedding/kernel", (P, P, 3, D))
+    put("embedding/bias", (D,))
+    put("Transformer/posembed_input/pos_embedding", (1, n_tok, D))
+    for i in range(L):
+        b = f"Transformer/encoderblock_{i}/"
+        for ln in ("LayerNorm_0", "LayerNorm_2"):
+            put(b + ln + "/scale", (D,))
+            put(b + ln + "/bias", (D,))
+        for nm in ("query", "key", "value"):
+            put(b + f"MultiHeadDotProductAttention_1/{nm}/kernel", (D, H, hd))
+            put(b + f"MultiHeadDotProductAttention_1/{nm}/bias", (H, hd))
+        put(b + "MultiHeadDotProductAttention_1/out/kernel", (H, hd, D))
+        put(b + "MultiHeadDotProductAttention_1/out/bias", (D,))
+        put(b + "MlpBlock_3/Dense_0/kernel", (D, M))
+        put(b + "MlpBlock_3/Dense_0/bias", (M,))
+        put(b + "MlpBlock_3/Dense_1/kernel", (M, D))
+        put(b + "MlpBlock_3/Dense_1/bias", (D,))
+    put("Transformer/encoder_norm/scale", (D,))
+    put("Transformer/encoder_norm/bias", (D,))
+    put("pre_logits/kernel", (D, D))
+    put("pre_logits/bias", (D,))
+    put("head/kernel", (D, ncls))
+    put("head/bias", (ncls,))
+    return z
+
+
+def convert_fixture():
+    z = flax_npz()
+    src = os.path.join(HERE, "flax_tiny.npz")
+    # np.savez stores keys in insertion order; np.load iterates sorted by the
+    # archive order, which is what converter.py relies on ("bias" before
+    # "kernel" for the attention entries), so write them sorted like a real
+    # Flax checkpoint does.
+    np.savez(src, **{k: z[k] for k in sorted(z)})
+    npz = np.load(src)
+    sd = ref_converter.convert(npz)
+    np.savez(os.path.join(HERE, "flax_tiny_converted.npz"),
+             **{k: np_(v) for k, v in sd.items()})
+    with open(os.path.join(HERE, "flax_tiny_converted.json"), "w") as f:
+        json.dump([[k, list(v.shape)] for k, v in sd.items()], f)
+    print("convert", len(sd), "keys")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    keys()
+    tiny()
+    convert_fixture()
+    full("s16_224_ref", "s16", 224, 8, "reference")
+    full("b16_224_ref", "b16", 224, 8, "reference")
+    full("b16_224_pert", "b16", 224, 4, "perturbed", seed=3)
+    full("b16_384_ref", "b16", 384, 4, "reference", pool=12)
+    full("l16_224_ref", "l16", 224, 4, "reference", pool=16)

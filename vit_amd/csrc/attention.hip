@@ -1,0 +1,243 @@
+// Flash-style multi-head self-attention forward for ViT token counts
+// (197 / 577 tokens, head_dim 64) on gfx950 / CDNA4.
+//
+// Reference semantics (models/transformer.py:42-46): per (image, head),
+//   P = softmax(q k^T * scaling) over keys, no mask;  ctx = P v,
+// with heads concatenated head-major along the channel dim of the output.
+//
+// One workgroup = one (image, head) and NW q-tiles of 32 rows, one wave per
+// q-tile.  The head's whole K and V ([ntok, 64] bf16 each) are staged once in
+// LDS; every wave then walks the keys in blocks of 32 with a wave-private
+// online softmax:
+//   S^T[key][q] = K_blk Q^T    (mfma 32x32x16, key on the MFMA row, q on the lane)
+//   running max / sum per q live in that lane's registers (both half-waves hold
+//   the same q, they exchange one value per block),
+//   O^T[d][q] += V_blk^T P^T   where the exponentiated S^T accumulator is, after
+//   packing to bf16, already the B operand of this product (its k order is
+//   key = 16s + 8(j>>2) + 4*(lane>>5) + (j&3) for element j of k-step s).
+// The [ntok, ntok] score matrix never exists in memory.
+#include "vitk_common.h"
+#include "vitk_kernels.h"
+
+namespace vitk {
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+constexpr float kMaskedScore = -1.0e30f;
+
+// VTR = true : V row-major in LDS, transposed fragments via ds_read_b64_tr_b16.
+// VTR = false: V stored transposed ([d][key]) in LDS, fragments via ds_read_b64.
+template <int NW, bool VTR>
+__global__ __launch_bounds__(NW * 64) void attention_fwd_hd64(const bf16_t* __restrict__ Q,
+                                                              const bf16_t* __restrict__ K,
+                                                              const bf16_t* __restrict__ V,
+                                                              bf16_t* __restrict__ O, int ntok, int heads,
+                                                              float scale_log2e) {
+    constexpr int HD = 64;
+    constexpr int RB = HD * 2;   // bytes per K/V row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int bh = blockIdx.x;   // image * heads + head
+    const int kblocks = (ntok + 31) >> 5;
+    const int kpad = kblocks * 32;
+    const int vts = kpad + 4;    // V^T row stride in elements (VTR = false)
+
+    char* k_lds = smem;
+    char* v_lds = smem + kpad * RB;
+
+    // ---- stage K and V of this head: 16-byte chunks, rows past ntok zero-filled.
+    // K slot = chunk ^ ((row >> 1) & 7)   (conflict-free ds_read_b128 of 32 rows x one chunk column)
+    // V slot = chunk ^ (((row >> 1) & 1) << 2)  (conflict-free transposed read of 4 rows x 64 B)
+    {
+        const bf16_t* kg = K + (size_t)bh * ntok * HD;
+        const bf16_t* vg = V + (size_t)bh * ntok * HD;
+        for (int cid = tid; cid < kpad * 8; cid += NW * 64) {
+            const int row = cid >> 3, c = cid & 7;
+            u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+            if (row < ntok) {
+                kv = *reinterpret_cast<const u32x4*>(kg + (size_t)row * HD + c * 8);
+                vv = *reinterpret_cast<const u32x4*>(vg + (size_t)row * HD + c * 8);
+            }
+            *reinterpret_cast<u32x4*>(k_lds + row * RB + ((c ^ ((row >> 1) & 7)) << 4)) = kv;
+            if constexpr (VTR) {
+                *reinterpret_cast<u32x4*>(v_lds + row * RB + ((c ^ (((row >> 1) & 1) << 2)) << 4)) = vv;
+            } else {
+                unsigned short* vt = reinterpret_cast<unsigned short*>(v_lds);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    vt[(c * 8 + 2 * j) * vts + row] = (unsigned short)(vv[j] & 0xFFFFu);
+                    vt[(c * 8 + 2 * j + 1) * vts + row] = (unsigned short)(vv[j] >> 16);
+                }
+            }
+        }
+    }
+
+    // ---- this wave's 32 query rows: B-operand fragments straight from global memory.
+    const int r = lane & 31, hh = lane >> 5;
+    const int q0 = (blockIdx.y * NW + wave) * 32;
+    const int qrow = q0 + r;
+    const int qld = qrow < ntok ? qrow : ntok - 1;   // padded rows re-read the last row; never stored
+    bf16x8 qf[4];
+    {
+        const bf16_t* qg = Q + ((size_t)bh * ntok + qld) * HD + hh * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qg + ks * 16);
+    }
+    __syncthreads();
+
+    f32x16 o_acc[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o_acc[d][i] = 0.f;
+    float m_run = kMaskedScore, l_run = 0.f;
+
+    const int kswz = (r >> 1) & 7;
+    // transposed-read lane roles: 16-lane group -> d sub-block, lane -> (key row, 4-column piece)
+    const int tsub = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
+
+    if (q0 < ntok) {   // wave-uniform: a wave whose whole q-tile is padding only took part in staging
+        for (int kb = 0; kb < kblocks; ++kb) {
+            // S^T block: 32 keys x 32 queries, K = head_dim in 4 steps of 16
+            f32x16 s;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[i] = 0.f;
+            const char* krow = k_lds + (kb * 32 + r) * RB;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + (((ks * 2 + hh) ^ kswz) << 4));
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+            }
+            // scores in log2 units; keys past ntok (last block only) are masked out
+            const int key0 = kb * 32 + 4 * hh;
+            float mx = kMaskedScore;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float v = s[i] * scale_log2e;
+                if (key0 + (i & 3) + 8 * (i >> 2) >= ntok) v = kMaskedScore;
+                s[i] = v;
+                mx = fmaxf(mx, v);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                s[i] = __builtin_amdgcn_exp2f(s[i] - m_new);
+                psum += s[i];
+            }
+            l_run = l_run * alpha + psum;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o_acc[d][i] *= alpha;
+            // P^T fragments (B operand), one per 16-key step
+            bf16x8 pf[2];
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                u32x4 pk = {pack_bf16(s[8 * st + 0], s[8 * st + 1]), pack_bf16(s[8 * st + 2], s[8 * st + 3]),
+                            pack_bf16(s[8 * st + 4], s[8 * st + 5]), pack_bf16(s[8 * st + 6], s[8 * st + 7])};
+                pf[st] = __builtin_bit_cast(bf16x8, pk);
+            }
+            // O^T[d][q] += V^T[d][key] P^T[key][q]
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    bf16x4 v0, v1;
+                    const int keyb = kb * 32 + 16 * st + 4 * hh;   // + 8t + (0..3)
+                    if constexpr (VTR) {
+                        const int chunk = d * 4 + tsub * 2 + (tp >> 1);
+                        const int ka = keyb + tq, kb2 = keyb + 8 + tq;
+                        const char* a0 = v_lds + ka * RB + ((chunk ^ (((ka >> 1) & 1) << 2)) << 4) + (tp & 1) * 8;
+                        const char* a1 = v_lds + kb2 * RB + ((chunk ^ (((kb2 >> 1) & 1) << 2)) << 4) + (tp & 1) * 8;
+                        v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a0);
+                        v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a1);
+                    } else {
+                        const bf16_t* vt = reinterpret_cast<const bf16_t*>(v_lds) + (d * 32 + r) * vts + keyb;
+                        v0 = *reinterpret_cast<const bf16x4*>(vt);
+                        v1 = *reinterpret_cast<const bf16x4*>(vt + 8);
+                    }
+                    const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[st], o_acc[d], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- normalise and store: lane holds q = qrow, d = 32*blk + 8g + 4*hh + (0..3)
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = 1.0f / l_tot;
+        if (qrow < ntok) {
+            const int b = bh / heads, h = bh - b * heads;
+            bf16_t* og = O + (((size_t)b * ntok + qrow) * heads + h) * HD + 4 * hh;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2 pk = {pack_bf16(o_acc[d][4 * g] * inv, o_acc[d][4 * g + 1] * inv),
+                                pack_bf16(o_acc[d][4 * g + 2] * inv, o_acc[d][4 * g + 3] * inv)};
+                    *reinterpret_cast<u32x2*>(og + d * 32 + 8 * g) = pk;
+                }
+        }
+    }
+}
+
+template <int NW, bool VTR>
+static hipError_t attn_launch(const void* q, const void* k, const void* v, void* out, int batch, int heads,
+                              int ntok, float scale, hipStream_t s) {
+    const int kpad = ((ntok + 31) / 32) * 32;
+    const size_t lds = VTR ? (size_t)kpad * 128 * 2 : (size_t)kpad * 128 + (size_t)64 * (kpad + 4) * 2;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {   // beyond the default dynamic-LDS limit the kernel must be told
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_fwd_hd64<NW, VTR>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const int qtiles = (ntok + 31) / 32;
+    dim3 grid(batch * heads, (qtiles + NW - 1) / NW), block(NW * 64);
+    hipLaunchKernelGGL((attention_fwd_hd64<NW, VTR>), grid, block, lds, s,
+                       reinterpret_cast<const bf16_t*>(q), reinterpret_cast<const bf16_t*>(k),
+                       reinterpret_cast<const bf16_t*>(v), reinterpret_cast<bf16_t*>(out), ntok, heads,
+                       scale * 1.44269504088896340736f);
+    return hipGetLastError();
+}
+
+hipError_t launch_attention(const void* q, const void* k, const void* v, void* out, int batch, int heads,
+                            int ntok, int hd, float scale, int variant, hipStream_t s) {
+    if (hd != 64 || ntok < 1) return hipErrorInvalidValue;
+    const int qtiles = (ntok + 31) / 32;
+    // Waves per workgroup (one 32-row q-tile each): a single workgroup per head when the
+    // q-tiles fit 7 waves (K/V staged once), else the width that leaves the fewest idle
+    // wave slots, larger on ties.
+    const bool tr = (variant & 1) == 0;
+    int nw = 4;
+    if (qtiles > 4 && qtiles <= 7) {
+        nw = 7;
+    } else if (qtiles > 7) {
+        int best = 1 << 30;
+        for (int c = 4; c <= 8; ++c) {
+            const int idle = ((qtiles + c - 1) / c) * c - qtiles;
+            if (idle <= best) { best = idle; nw = c; }
+        }
+    }
+#define VITK_ATTN_CASE(NWV)                                                                    \
+    case NWV:                                                                                  \
+        return tr ? attn_launch<NWV, true>(q, k, v, out, batch, heads, ntok, scale, s)         \
+                  : attn_launch<NWV, false>(q, k, v, out, batch, heads, ntok, scale, s);
+    switch (nw) {
+        VITK_ATTN_CASE(4)
+        VITK_ATTN_CASE(5)
+        VITK_ATTN_CASE(6)
+        VITK_ATTN_CASE(7)
+        VITK_ATTN_CASE(8)
+    }
+#undef VITK_ATTN_CASE
+    return hipErrorInvalidValue;
+}
+
+}  // namespace vitk

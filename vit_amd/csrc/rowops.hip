@@ -1,0 +1,134 @@
+// Bandwidth-bound row kernels of the ViT forward path (gfx950 / CDNA4):
+// LayerNorm over the fp32 residual stream, the cls-token row, and the
+// fp32 -> bf16 image cast.
+#include "vitk_common.h"
+#include "vitk_kernels.h"
+
+namespace vitk {
+
+// ---------------------------------------------------------------------------
+// LayerNorm (nn.LayerNorm(D, eps): models/transformer.py:56,60,93): per row,
+// mean and biased variance in fp32, y = (x - mean) * rsqrt(var + eps) * g + b.
+// One wave owns one row: each lane keeps NV float4 of it in registers, so the
+// row is read from HBM exactly once (4*D bytes) and written once (2*D bytes as
+// bf16, the next GEMM's operand type).  Two-pass statistics on the register
+// copy (mean first, then centred squares) match torch's numerics closely.
+// ---------------------------------------------------------------------------
+template <int NV, bool OUT_BF16>
+__global__ __launch_bounds__(256) void layernorm_rows(const float* __restrict__ x, int64_t x_stride,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, void* __restrict__ y,
+                                                      int64_t y_stride, int rows, float eps) {
+    constexpr int D = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int waves_total = gridDim.x * 4;
+    f32x4 g[NV], b[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        g[i] = *reinterpret_cast<const f32x4*>(gamma + i * 256 + lane * 4);
+        b[i] = *reinterpret_cast<const f32x4*>(beta + i * 256 + lane * 4);
+    }
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += waves_total) {
+        const float* xr = x + (int64_t)row * x_stride;
+        f32x4 v[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const f32x4*>(xr + i * 256 + lane * 4);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        const float mean = wave_sum(s) * (1.0f / D);
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = v[i][j] - mean;
+                ss += d * d;
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(ss) * (1.0f / D) + eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[i][j] + b[i][j];
+            if constexpr (OUT_BF16) {
+                u32x2 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
+                *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(y) + (int64_t)row * y_stride + i * 256 +
+                                          lane * 4) = pk;
+            } else {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(y) + (int64_t)row * y_stride + i * 256 +
+                                          lane * 4) = o;
+            }
+        }
+    }
+}
+
+template <int NV>
+static hipError_t ln_launch(const float* x, int64_t xs, const float* g, const float* b, void* y, int64_t ys,
+                            int rows, float eps, bool out_bf16, hipStream_t s) {
+    int blocks = (rows + 3) / 4;
+    if (blocks > 4096) blocks = 4096;   // grid-stride beyond 16 row-waves per CU
+    if (out_bf16)
+        hipLaunchKernelGGL((layernorm_rows<NV, true>), dim3(blocks), dim3(256), 0, s, x, xs, g, b, y, ys, rows, eps);
+    else
+        hipLaunchKernelGGL((layernorm_rows<NV, false>), dim3(blocks), dim3(256), 0, s, x, xs, g, b, y, ys, rows, eps);
+    return hipGetLastError();
+}
+
+hipError_t launch_layernorm(const float* x, int64_t x_row_stride, const float* gamma, const float* beta,
+                            void* y, int64_t y_row_stride, int rows, int D, float eps, bool out_bf16,
+                            hipStream_t s) {
+    switch (D) {
+        case 256: return ln_launch<1>(x, x_row_stride, gamma, beta, y, y_row_stride, rows, eps, out_bf16, s);
+        case 512: return ln_launch<2>(x, x_row_stride, gamma, beta, y, y_row_stride, rows, eps, out_bf16, s);
+        case 768: return ln_launch<3>(x, x_row_stride, gamma, beta, y, y_row_stride, rows, eps, out_bf16, s);
+        case 1024: return ln_launch<4>(x, x_row_stride, gamma, beta, y, y_row_stride, rows, eps, out_bf16, s);
+        case 1280: return ln_launch<5>(x, x_row_stride, gamma, beta, y, y_row_stride, rows, eps, out_bf16, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// x[b, 0, :] = cls_token + pos_embed[0]   (vision_transformer.py:48-50)
+__global__ void cls_pos_rows(const float* __restrict__ cls, const float* __restrict__ pos,
+                             float* __restrict__ x, int batch, int ntok, int D) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // float4 index inside a row
+    const int b = blockIdx.y;
+    if (i * 4 < D) {
+        const f32x4 c = *reinterpret_cast<const f32x4*>(cls + i * 4);
+        const f32x4 p = *reinterpret_cast<const f32x4*>(pos + i * 4);
+        *reinterpret_cast<f32x4*>(x + (size_t)b * ntok * D + i * 4) = c + p;
+    }
+}
+
+hipError_t launch_cls_pos(const float* cls, const float* pos, float* x, int batch, int ntok, int D,
+                          hipStream_t s) {
+    dim3 grid((D / 4 + 255) / 256, batch);
+    hipLaunchKernelGGL(cls_pos_rows, grid, dim3(256), 0, s, cls, pos, x, batch, ntok, D);
+    return hipGetLastError();
+}
+
+// fp32 -> bf16, 8 elements (32 B in, 16 B out) per lane per step; n % 8 == 0.
+__global__ __launch_bounds__(256) void cast_f32_bf16(const float* __restrict__ in, bf16_t* __restrict__ out,
+                                                     int64_t n8) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(in + i * 8);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(in + i * 8 + 4);
+        u32x4 o = {pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3]), pack_bf16(b[0], b[1]), pack_bf16(b[2], b[3])};
+        *reinterpret_cast<u32x4*>(out + i * 8) = o;
+    }
+}
+
+hipError_t launch_cast_f32_bf16(const float* in, void* out, int64_t n, hipStream_t s) {
+    const int64_t n8 = n / 8;
+    int64_t blocks = (n8 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(cast_f32_bf16, dim3((unsigned)blocks), dim3(256), 0, s, in,
+                       reinterpret_cast<bf16_t*>(out), n8);
+    return hipGetLastError();
+}
+
+}  // namespace vitk

@@ -1,0 +1,177 @@
+// C ABI of the ViT forward kernels: argument checks, kernel selection, error
+// reporting.  Declarations and the reference call sites each entry point
+// replaces are in include/vitk.h.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/vitk.h"
+#include "vitk_kernels.h"
+
+using namespace vitk;
+
+namespace {
+
+thread_local char g_err[256] = "";
+int g_gemm_variant = 0;
+int g_attn_variant = 0;
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int launched(hipError_t e, const char* what) {
+    if (e == hipSuccess) return VITK_OK;
+    return fail(VITK_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+int ilog2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+// Shared path of the four dense entry points.
+int dense(const char* name, const void* A, const void* W, const float* bias, const float* resid, void* out,
+          int M, int N, int K, int epilogue, void* stream) {
+    if (!A || !W || !out) return fail(VITK_ERR_INVALID, "%s: null pointer", name);
+    if (M <= 0 || N <= 0 || K <= 0) return fail(VITK_ERR_INVALID, "%s: non-positive size %dx%dx%d", name, M, N, K);
+    if (!aligned16(A) || !aligned16(W) || !aligned16(out) || (bias && !aligned16(bias)) ||
+        (resid && !aligned16(resid)))
+        return fail(VITK_ERR_INVALID, "%s: pointers must be 16-byte aligned", name);
+    if (K % 32 != 0) return fail(VITK_ERR_UNSUPPORTED, "%s: K=%d is not a multiple of 32", name, K);
+    GemmArgs a = {};
+    a.A = A; a.W = W; a.bias = bias; a.out = out; a.resid = resid;
+    a.M = M; a.N = N; a.K = K; a.lda = K; a.ldo = N;
+    const bool tiled_ok = (N % 256 == 0) && (K % 64 == 0) && M >= 128 && g_gemm_variant != 2;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (tiled_ok) return launched(launch_gemm_tiled(a, epilogue, false, g_gemm_variant, s), name);
+    return launched(launch_gemm_small(a, epilogue, s), name);
+}
+
+}  // namespace
+
+extern "C" {
+
+int vitk_version(void) { return 1; }
+
+const char* vitk_last_error(void) { return g_err; }
+
+void vitk_set_debug_variant(int gemm_variant, int attention_variant) {
+    g_gemm_variant = gemm_variant;
+    g_attn_variant = attention_variant;
+}
+
+int vitk_layernorm(const float* x, int64_t x_row_stride, const float* gamma, const float* beta, void* y,
+                   int64_t y_row_stride, int rows, int D, float eps, int out_dtype, void* stream) {
+    if (!x || !gamma || !beta || !y) return fail(VITK_ERR_INVALID, "vitk_layernorm: null pointer");
+    if (rows <= 0) return fail(VITK_ERR_INVALID, "vitk_layernorm: rows=%d", rows);
+    if (out_dtype != VITK_F32 && out_dtype != VITK_BF16)
+        return fail(VITK_ERR_UNSUPPORTED, "vitk_layernorm: out_dtype=%d", out_dtype);
+    if (D % 256 != 0 || D < 256 || D > 1280)
+        return fail(VITK_ERR_UNSUPPORTED, "vitk_layernorm: D=%d (supported: 256..1280 in steps of 256)", D);
+    if (!aligned16(x) || !aligned16(gamma) || !aligned16(beta) || !aligned16(y) || x_row_stride % 4 != 0 ||
+        y_row_stride % 4 != 0 || x_row_stride < D || y_row_stride < D)
+        return fail(VITK_ERR_INVALID, "vitk_layernorm: misaligned pointer or row stride");
+    return launched(launch_layernorm(x, x_row_stride, gamma, beta, y, y_row_stride, rows, D, eps,
+                                     out_dtype == VITK_BF16, reinterpret_cast<hipStream_t>(stream)),
+                    "vitk_layernorm");
+}
+
+int vitk_cast_f32_bf16(const float* in, void* out, int64_t n, void* stream) {
+    if (!in || !out) return fail(VITK_ERR_INVALID, "vitk_cast_f32_bf16: null pointer");
+    if (n <= 0 || n % 8 != 0) return fail(VITK_ERR_INVALID, "vitk_cast_f32_bf16: n=%lld must be a positive multiple of 8", (long long)n);
+    if (!aligned16(in) || !aligned16(out)) return fail(VITK_ERR_INVALID, "vitk_cast_f32_bf16: misaligned pointer");
+    return launched(launch_cast_f32_bf16(in, out, n, reinterpret_cast<hipStream_t>(stream)), "vitk_cast_f32_bf16");
+}
+
+int vitk_patch_embed(const void* img, const void* w, const float* bias, const float* cls, const float* pos,
+                     float* x, int batch, int img_h, int img_w, int patch, int D, void* stream) {
+    if (!img || !w || !bias || !cls || !pos || !x) return fail(VITK_ERR_INVALID, "vitk_patch_embed: null pointer");
+    if (batch <= 0 || img_h <= 0 || img_w <= 0 || patch <= 0 || D <= 0)
+        return fail(VITK_ERR_INVALID, "vitk_patch_embed: non-positive size");
+    if (!aligned16(img) || !aligned16(w) || !aligned16(bias) || !aligned16(cls) || !aligned16(pos) || !aligned16(x))
+        return fail(VITK_ERR_INVALID, "vitk_patch_embed: pointers must be 16-byte aligned");
+    if (!is_pow2(patch) || patch < 8)
+        return fail(VITK_ERR_UNSUPPORTED, "vitk_patch_embed: patch=%d (needs a power of two >= 8)", patch);
+    if (img_w % 8 != 0) return fail(VITK_ERR_UNSUPPORTED, "vitk_patch_embed: img_w=%d not a multiple of 8", img_w);
+    if (D % 256 != 0) return fail(VITK_ERR_UNSUPPORTED, "vitk_patch_embed: D=%d not a multiple of 256", D);
+    const int gh = img_h / patch, gw = img_w / patch;   // Conv2d without padding floors
+    if (gh < 1 || gw < 1) return fail(VITK_ERR_INVALID, "vitk_patch_embed: image smaller than one patch");
+    GemmArgs a = {};
+    a.A = img; a.W = w; a.bias = bias; a.out = x; a.pos = pos;
+    a.npatch = gh * gw; a.ntok = a.npatch + 1; a.grid_w = gw;
+    a.M = batch * a.npatch; a.N = D; a.K = 3 * patch * patch;
+    a.lda = 0; a.ldo = D; a.batch = batch;
+    a.img_h = img_h; a.img_w = img_w; a.p_log2 = ilog2(patch);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int rc = launched(launch_cls_pos(cls, pos, x, batch, a.ntok, D, s), "vitk_patch_embed(cls)");
+    if (rc) return rc;
+    return launched(launch_gemm_tiled(a, EPI_PATCH_F32, true, g_gemm_variant == 1 ? 1 : 0, s), "vitk_patch_embed");
+}
+
+int vitk_gemm_bias(const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                   int out_dtype, void* stream) {
+    if (out_dtype != VITK_F32 && out_dtype != VITK_BF16)
+        return fail(VITK_ERR_UNSUPPORTED, "vitk_gemm_bias: out_dtype=%d", out_dtype);
+    return dense("vitk_gemm_bias", A, W, bias, nullptr, out, M, N, K,
+                 out_dtype == VITK_F32 ? EPI_BIAS_F32 : EPI_BIAS_BF16, stream);
+}
+
+int vitk_gemm_bias_gelu(const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                        void* stream) {
+    return dense("vitk_gemm_bias_gelu", A, W, bias, nullptr, out, M, N, K, EPI_BIAS_GELU_BF16, stream);
+}
+
+int vitk_gemm_bias_tanh(const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                        void* stream) {
+    return dense("vitk_gemm_bias_tanh", A, W, bias, nullptr, out, M, N, K, EPI_BIAS_TANH_BF16, stream);
+}
+
+int vitk_gemm_bias_residual(const void* A, const void* W, const float* bias, const float* resid, float* out,
+                            int M, int N, int K, void* stream) {
+    if (!resid) return fail(VITK_ERR_INVALID, "vitk_gemm_bias_residual: null residual");
+    return dense("vitk_gemm_bias_residual", A, W, bias, resid, out, M, N, K, EPI_BIAS_RESID_F32, stream);
+}
+
+int vitk_qkv_proj(const void* A, const void* W, const float* bias, void* qkv, int batch, int ntok, int heads,
+                  int hd, void* stream) {
+    if (!A || !W || !qkv) return fail(VITK_ERR_INVALID, "vitk_qkv_proj: null pointer");
+    if (batch <= 0 || ntok <= 0 || heads <= 0 || hd <= 0)
+        return fail(VITK_ERR_INVALID, "vitk_qkv_proj: non-positive size");
+    if (!aligned16(A) || !aligned16(W) || !aligned16(qkv) || (bias && !aligned16(bias)))
+        return fail(VITK_ERR_INVALID, "vitk_qkv_proj: pointers must be 16-byte aligned");
+    const int D = heads * hd;
+    if (hd % 8 != 0) return fail(VITK_ERR_UNSUPPORTED, "vitk_qkv_proj: hd=%d not a multiple of 8", hd);
+    if ((3 * D) % 256 != 0 || D % 64 != 0)
+        return fail(VITK_ERR_UNSUPPORTED, "vitk_qkv_proj: D=%d (needs 3*D %% 256 == 0 and D %% 64 == 0)", D);
+    GemmArgs a = {};
+    a.A = A; a.W = W; a.bias = bias; a.out = qkv;
+    a.M = batch * ntok; a.N = 3 * D; a.K = D; a.lda = D; a.ldo = 0;
+    a.ntok = ntok; a.heads = heads; a.hd = hd; a.batch = batch;
+    return launched(launch_gemm_tiled(a, EPI_QKV_BF16, false, g_gemm_variant == 1 ? 1 : 0,
+                                      reinterpret_cast<hipStream_t>(stream)),
+                    "vitk_qkv_proj");
+}
+
+int vitk_attention(const void* q, const void* k, const void* v, void* ctx, int batch, int heads, int ntok,
+                   int hd, float scale, void* stream) {
+    if (!q || !k || !v || !ctx) return fail(VITK_ERR_INVALID, "vitk_attention: null pointer");
+    if (batch <= 0 || heads <= 0 || ntok <= 0) return fail(VITK_ERR_INVALID, "vitk_attention: non-positive size");
+    if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(ctx))
+        return fail(VITK_ERR_INVALID, "vitk_attention: pointers must be 16-byte aligned");
+    if (hd != 64) return fail(VITK_ERR_UNSUPPORTED, "vitk_attention: hd=%d (only 64 is implemented)", hd);
+    if (ntok > 608) return fail(VITK_ERR_UNSUPPORTED, "vitk_attention: ntok=%d exceeds the LDS-resident limit 608", ntok);
+    return launched(launch_attention(q, k, v, ctx, batch, heads, ntok, hd, scale, g_attn_variant,
+                                     reinterpret_cast<hipStream_t>(stream)),
+                    "vitk_attention");
+}
+
+}  // extern "C"

@@ -1,0 +1,43 @@
+// Internal launch interface between the C ABI (vitk_api.hip) and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vitk {
+
+enum Epilogue {
+    EPI_BIAS_BF16 = 0,       // out bf16 [M,N] = acc + bias
+    EPI_BIAS_GELU_BF16 = 1,  // out bf16 [M,N] = gelu(acc + bias)
+    EPI_BIAS_RESID_F32 = 2,  // out f32  [M,N] = resid + acc + bias
+    EPI_QKV_BF16 = 3,        // out bf16 [3,B,H,Ntok,hd] <- (acc + bias)[b*Ntok+t, which*D + h*hd + e]
+    EPI_PATCH_F32 = 4,       // out f32  [B,Ntok,N] row b*Ntok+1+p = acc + bias + pos[1+p]
+    EPI_BIAS_F32 = 5,        // out f32  [M,N] = acc + bias
+    EPI_BIAS_TANH_BF16 = 6,  // out bf16 [M,N] = tanh(acc + bias)
+};
+
+struct GemmArgs {
+    const void* A;       // bf16 activations [M,K] (row stride lda), or the bf16 image for the gather loader
+    const void* W;       // bf16 weights [N,K], row-major
+    const float* bias;   // [N] or nullptr
+    void* out;
+    const float* resid;  // EPI_BIAS_RESID_F32 (may alias out)
+    const float* pos;    // EPI_PATCH_F32: pos_embed [Ntok,N]
+    int M, N, K;
+    int lda, ldo;        // row strides in elements
+    int ntok, heads, hd, batch;                 // EPI_QKV_BF16 / EPI_PATCH_F32
+    int img_h, img_w, p_log2, grid_w, npatch;   // gather loader
+};
+
+// Every launcher returns hipSuccess or the launch error; shape checks are the caller's job.
+hipError_t launch_gemm_tiled(const GemmArgs& a, int epilogue, bool gather, int variant, hipStream_t s);
+hipError_t launch_gemm_small(const GemmArgs& a, int epilogue, hipStream_t s);
+hipError_t launch_layernorm(const float* x, int64_t x_row_stride, const float* gamma, const float* beta,
+                            void* y, int64_t y_row_stride, int rows, int D, float eps, bool out_bf16,
+                            hipStream_t s);
+hipError_t launch_cls_pos(const float* cls, const float* pos, float* x, int batch, int ntok, int D,
+                          hipStream_t s);
+hipError_t launch_cast_f32_bf16(const float* in, void* out, int64_t n, hipStream_t s);
+hipError_t launch_attention(const void* q, const void* k, const void* v, void* out, int batch, int heads,
+                            int ntok, int hd, float scale, int variant, hipStream_t s);
+
+}  // namespace vitk

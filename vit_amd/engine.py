@@ -1,0 +1,91 @@
+"""Device-side state of a VisionTransformer: kernel-ready weights and workspaces.
+
+The nn.Module keeps the reference's fp32 parameters (so `state_dict()` and
+`load_state_dict()` are unchanged); the kernels want bf16 GEMM weights and
+fp32 vectors at fixed layouts.  `WeightCache` derives those once and
+re-derives them when a parameter is modified or replaced.  `Workspace` owns the
+activation buffers of one (batch, tokens) shape so that steady-state forwards
+allocate nothing.
+
+HBM layout of one forward (B images, N tokens, D channels, M = mlp width):
+  x    f32  [B*N, D]      residual stream (kept fp32: bf16 here costs > 1e-2 logit error)
+  y    bf16 [B*N, D]      LayerNorm output = GEMM operand
+  qkv  bf16 [3, B, H, N, hd]  head-major q, k, v
+  ctx  bf16 [B*N, D]      attention output, heads concatenated
+  h    bf16 [B*N, M]      GELU(fc1) output
+"""
+import torch
+
+
+def _f32(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _bf16(t):
+    return t.detach().to(torch.bfloat16).contiguous()
+
+
+class WeightCache:
+    def __init__(self, model):
+        self._model = model
+        self._key = None
+        self.t = {}
+
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version, p.device) for p in self._model.parameters())
+
+    def get(self):
+        key = self._signature()
+        if key != self._key:
+            self._rebuild()
+            self._key = key
+        return self.t
+
+    def _rebuild(self):
+        m = self._model
+        t = {}
+        D = m.hidden_size
+        t["embed.w"] = _bf16(m.embedding.weight).reshape(D, -1)          # OIHW flattened: k = c*P*P + i*P + j
+        t["embed.b"] = _f32(m.embedding.bias)
+        t["cls"] = _f32(m.cls_token).reshape(D)
+        t["pos"] = _f32(m.pos_embed).reshape(-1, D)
+        for i, blk in enumerate(m.encoder.blocks):
+            p = f"b{i}."
+            for ln in ("norm1", "norm2"):
+                mod = getattr(blk, ln)
+                t[p + ln + ".w"], t[p + ln + ".b"] = _f32(mod.weight), _f32(mod.bias)
+            att = blk.attention
+            t[p + "qkv.w"] = _bf16(att.in_proj.weight)
+            t[p + "qkv.b"] = None if att.in_proj.bias is None else _f32(att.in_proj.bias)
+            t[p + "out.w"], t[p + "out.b"] = _bf16(att.out_proj.weight), _f32(att.out_proj.bias)
+            t[p + "fc1.w"], t[p + "fc1.b"] = _bf16(blk.mlp.fc1.weight), _f32(blk.mlp.fc1.bias)
+            t[p + "fc2.w"], t[p + "fc2.b"] = _bf16(blk.mlp.fc2.weight), _f32(blk.mlp.fc2.bias)
+        t["norm.w"], t["norm.b"] = _f32(m.encoder.norm.weight), _f32(m.encoder.norm.bias)
+        if isinstance(m.pre_logits, torch.nn.Linear):
+            t["pre.w"], t["pre.b"] = _bf16(m.pre_logits.weight), _f32(m.pre_logits.bias)
+        t["head.w"], t["head.b"] = _bf16(m.head.weight), _f32(m.head.bias)
+        self.t = t
+
+
+class Workspace:
+    """Activation buffers for one (B, N, D, H, M, classes) shape on one device."""
+
+    def __init__(self, device, B, N, D, H, M, ncls):
+        bf, f32 = torch.bfloat16, torch.float32
+        hd = D // H
+        e = lambda *s, dtype: torch.empty(*s, dtype=dtype, device=device)   # noqa: E731
+        self.shape = (B, N, D, H, M, ncls)
+        self.x = e(B, N, D, dtype=f32)
+        self.y = e(B * N, D, dtype=bf)
+        self.qkv = e(3, B, H, N, hd, dtype=bf)
+        self.ctx = e(B, N, D, dtype=bf)
+        self.h = e(B * N, M, dtype=bf)
+        self.cls_n = e(B, D, dtype=bf)
+        self.pre = e(B, D, dtype=bf)
+        self.logits = e(B, ncls, dtype=f32)
+        self.img16 = None
+
+    def image_buffer(self, like):
+        if self.img16 is None or self.img16.shape != like.shape:
+            self.img16 = torch.empty(like.shape, dtype=torch.bfloat16, device=like.device)
+        return self.img16

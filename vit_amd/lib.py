@@ -1,0 +1,71 @@
+"""ctypes binding of libvitk.so (the C ABI declared in include/vitk.h).
+
+The library is the only compute back end of this package: if it is missing or
+a call fails, the caller gets an exception, never a silent fallback.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvitk.so")
+
+VITK_F32, VITK_BF16 = 0, 1
+ABI_VERSION = 1
+
+_p = ctypes.c_void_p
+_i = ctypes.c_int
+_i64 = ctypes.c_int64
+_f = ctypes.c_float
+
+# name -> argument types; every function returns int except where noted.
+SIGNATURES = {
+    "vitk_layernorm": [_p, _i64, _p, _p, _p, _i64, _i, _i, _f, _i, _p],
+    "vitk_cast_f32_bf16": [_p, _p, _i64, _p],
+    "vitk_patch_embed": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "vitk_gemm_bias": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "vitk_gemm_bias_gelu": [_p, _p, _p, _p, _i, _i, _i, _p],
+    "vitk_gemm_bias_tanh": [_p, _p, _p, _p, _i, _i, _i, _p],
+    "vitk_gemm_bias_residual": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "vitk_qkv_proj": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "vitk_attention": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
+}
+EXPORTS = sorted(list(SIGNATURES) + ["vitk_version", "vitk_last_error", "vitk_set_debug_variant"])
+
+_lib = None
+
+
+class VitkError(RuntimeError):
+    """A libvitk entry point returned a non-zero code."""
+
+
+def load():
+    """Load libvitk.so once and attach argument/return types."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VitkError(
+            f"{LIB_PATH} is missing: build it with `python -m vit_amd.build` "
+            "(there is no CPU or eager fallback for the ViT forward path)")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.vitk_version.restype = _i
+    lib.vitk_version.argtypes = []
+    lib.vitk_last_error.restype = ctypes.c_char_p
+    lib.vitk_last_error.argtypes = []
+    lib.vitk_set_debug_variant.restype = None
+    lib.vitk_set_debug_variant.argtypes = [_i, _i]
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = _i
+        fn.argtypes = args
+    v = lib.vitk_version()
+    if v != ABI_VERSION:
+        raise VitkError(f"libvitk ABI version {v}, expected {ABI_VERSION}: rebuild with `python -m vit_amd.build --force`")
+    _lib = lib
+    return lib
+
+
+def check(rc, lib=None):
+    if rc != 0:
+        lib = lib or load()
+        raise VitkError(f"libvitk error {rc}: {lib.vitk_last_error().decode()}")

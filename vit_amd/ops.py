@@ -1,0 +1,183 @@
+"""Tensor-level wrappers over the libvitk C ABI.
+
+Each function checks device/dtype/contiguity, passes raw device pointers and
+the current HIP stream to the matching `vitk_*` entry point (include/vitk.h)
+and raises on any non-zero return.  torch is used for memory and streams only.
+"""
+import torch
+
+from . import lib as _lib
+
+_event_hook = None   # optional callable(name) -> context manager, set by bench.py for per-kernel timing
+
+
+def set_event_hook(hook):
+    """Install `hook(name)` (a context-manager factory) around every kernel call, or None."""
+    global _event_hook
+    _event_hook = hook
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NULL = _Null()
+
+
+def _span(name):
+    return _event_hook(name) if _event_hook is not None else _NULL
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, dtype, name):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise _lib.VitkError(f"{name} must be a CUDA/HIP tensor: the ViT forward path has no CPU fallback")
+    if t.dtype != dtype:
+        raise _lib.VitkError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.VitkError(f"{name} must be contiguous")
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def layernorm(x, gamma, beta, eps, out, rows=None, x_row_stride=None):
+    """out[r] = LN(x[r]); x f32 [..., D] (or strided rows), out bf16/f32 [rows, D]."""
+    L = _lib.load()
+    D = gamma.numel()
+    _chk(gamma, torch.float32, "gamma")
+    _chk(beta, torch.float32, "beta")
+    if x.dtype != torch.float32 or not x.is_cuda:
+        raise _lib.VitkError("layernorm: x must be a CUDA float32 tensor")
+    if rows is None:
+        _chk(x, torch.float32, "x")
+        rows = x.numel() // D
+        x_row_stride = D
+    _chk(out, out.dtype, "out")
+    od = _lib.VITK_BF16 if out.dtype == torch.bfloat16 else _lib.VITK_F32
+    with _span("layernorm"):
+        _lib.check(L.vitk_layernorm(_ptr(x), x_row_stride, _ptr(gamma), _ptr(beta), _ptr(out), D, rows, D,
+                                    float(eps), od, _stream()), L)
+    return out
+
+
+def cast_bf16(x, out=None):
+    L = _lib.load()
+    _chk(x, torch.float32, "x")
+    if out is None:
+        out = torch.empty_like(x, dtype=torch.bfloat16)
+    _chk(out, torch.bfloat16, "out")
+    with _span("cast"):
+        _lib.check(L.vitk_cast_f32_bf16(_ptr(x), _ptr(out), x.numel(), _stream()), L)
+    return out
+
+
+def patch_embed(img, w, bias, cls, pos, out, patch):
+    """img bf16 [B,3,H,W]; w bf16 [D,3*P*P]; out f32 [B,ntok,D]."""
+    L = _lib.load()
+    _chk(img, torch.bfloat16, "img")
+    _chk(w, torch.bfloat16, "w")
+    for n, t in (("bias", bias), ("cls", cls), ("pos", pos), ("out", out)):
+        _chk(t, torch.float32, n)
+    B, C, H, W = img.shape
+    D = w.shape[0]
+    if C != 3 or w.shape[1] != 3 * patch * patch:
+        raise _lib.VitkError(f"patch_embed: weight {tuple(w.shape)} does not match 3x{patch}x{patch} patches")
+    ntok = (H // patch) * (W // patch) + 1
+    if tuple(out.shape) != (B, ntok, D) or pos.numel() != ntok * D:
+        raise _lib.VitkError(f"patch_embed: out {tuple(out.shape)} / pos {tuple(pos.shape)} do not match "
+                             f"[{B},{ntok},{D}]")
+    with _span("patch_embed"):
+        _lib.check(L.vitk_patch_embed(_ptr(img), _ptr(w), _ptr(bias), _ptr(cls), _ptr(pos), _ptr(out),
+                                      B, H, W, patch, D, _stream()), L)
+    return out
+
+
+def _dense_shapes(a, w, out, name):
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K or tuple(out.shape) != (M, N):
+        raise _lib.VitkError(f"{name}: shapes A{tuple(a.shape)} W{tuple(w.shape)} out{tuple(out.shape)}")
+    return M, N, K
+
+
+def gemm_bias(a, w, bias, out):
+    L = _lib.load()
+    _chk(a, torch.bfloat16, "A"); _chk(w, torch.bfloat16, "W"); _chk(bias, torch.float32, "bias")
+    _chk(out, out.dtype, "out")
+    M, N, K = _dense_shapes(a, w, out, "gemm_bias")
+    od = _lib.VITK_BF16 if out.dtype == torch.bfloat16 else _lib.VITK_F32
+    with _span("gemm_bias"):
+        _lib.check(L.vitk_gemm_bias(_ptr(a), _ptr(w), _ptr(bias), _ptr(out), M, N, K, od, _stream()), L)
+    return out
+
+
+def gemm_bias_gelu(a, w, bias, out):
+    L = _lib.load()
+    _chk(a, torch.bfloat16, "A"); _chk(w, torch.bfloat16, "W"); _chk(bias, torch.float32, "bias")
+    _chk(out, torch.bfloat16, "out")
+    M, N, K = _dense_shapes(a, w, out, "gemm_bias_gelu")
+    with _span("gemm_bias_gelu"):
+        _lib.check(L.vitk_gemm_bias_gelu(_ptr(a), _ptr(w), _ptr(bias), _ptr(out), M, N, K, _stream()), L)
+    return out
+
+
+def gemm_bias_tanh(a, w, bias, out):
+    L = _lib.load()
+    _chk(a, torch.bfloat16, "A"); _chk(w, torch.bfloat16, "W"); _chk(bias, torch.float32, "bias")
+    _chk(out, torch.bfloat16, "out")
+    M, N, K = _dense_shapes(a, w, out, "gemm_bias_tanh")
+    with _span("gemm_bias_tanh"):
+        _lib.check(L.vitk_gemm_bias_tanh(_ptr(a), _ptr(w), _ptr(bias), _ptr(out), M, N, K, _stream()), L)
+    return out
+
+
+def gemm_bias_residual(a, w, bias, resid, out):
+    """out f32 = resid + a @ w.T + bias; `out` may be `resid` itself."""
+    L = _lib.load()
+    _chk(a, torch.bfloat16, "A"); _chk(w, torch.bfloat16, "W"); _chk(bias, torch.float32, "bias")
+    _chk(resid, torch.float32, "resid"); _chk(out, torch.float32, "out")
+    M, N, K = _dense_shapes(a, w, out, "gemm_bias_residual")
+    if tuple(resid.shape) != (M, N):
+        raise _lib.VitkError(f"gemm_bias_residual: resid {tuple(resid.shape)} vs out [{M},{N}]")
+    with _span("gemm_bias_residual"):
+        _lib.check(L.vitk_gemm_bias_residual(_ptr(a), _ptr(w), _ptr(bias), _ptr(resid), _ptr(out), M, N, K,
+                                             _stream()), L)
+    return out
+
+
+def qkv_proj(a, w, bias, qkv, batch, ntok, heads, hd):
+    """a bf16 [batch*ntok, D]; qkv bf16 [3, batch, heads, ntok, hd]."""
+    L = _lib.load()
+    _chk(a, torch.bfloat16, "A"); _chk(w, torch.bfloat16, "W"); _chk(bias, torch.float32, "bias")
+    _chk(qkv, torch.bfloat16, "qkv")
+    D = heads * hd
+    if tuple(a.shape) != (batch * ntok, D) or tuple(w.shape) != (3 * D, D) or \
+            tuple(qkv.shape) != (3, batch, heads, ntok, hd):
+        raise _lib.VitkError(f"qkv_proj: shapes A{tuple(a.shape)} W{tuple(w.shape)} qkv{tuple(qkv.shape)}")
+    with _span("qkv_proj"):
+        _lib.check(L.vitk_qkv_proj(_ptr(a), _ptr(w), _ptr(bias), _ptr(qkv), batch, ntok, heads, hd, _stream()), L)
+    return qkv
+
+
+def attention(qkv, ctx, scale):
+    """qkv bf16 [3, B, H, N, hd] -> ctx bf16 [B, N, H*hd]."""
+    L = _lib.load()
+    _chk(qkv, torch.bfloat16, "qkv"); _chk(ctx, torch.bfloat16, "ctx")
+    _, B, H, N, hd = qkv.shape
+    if tuple(ctx.shape) != (B, N, H * hd):
+        raise _lib.VitkError(f"attention: ctx {tuple(ctx.shape)} vs [{B},{N},{H * hd}]")
+    with _span("attention"):
+        _lib.check(L.vitk_attention(_ptr(qkv[0]), _ptr(qkv[1]), _ptr(qkv[2]), _ptr(ctx), B, H, N, hd,
+                                    float(scale), _stream()), L)
+    return ctx

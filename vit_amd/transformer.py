@@ -1,0 +1,118 @@
+"""Encoder blocks with the reference's module tree, executed by libvitk kernels.
+
+Mirrors /root/reference/models/transformer.py: class names, constructor
+arguments, attribute names (and therefore state_dict keys) are identical, so a
+checkpoint for the reference loads unchanged.  The parameters live in ordinary
+nn.Linear / nn.LayerNorm containers; `forward` never calls those modules'
+own forward: every op is a HIP kernel reached through vit_amd.ops.
+
+Data flow of one block (models/transformer.py:66-76), x = fp32 residual stream:
+    y   = LN1(x)                      -> bf16        vitk_layernorm
+    qkv = y W_in^T + b, split by head -> bf16        vitk_qkv_proj
+    ctx = softmax(q k^T s) v          -> bf16        vitk_attention
+    x   = x + ctx W_out^T + b         -> fp32        vitk_gemm_bias_residual
+    y   = LN2(x)                      -> bf16        vitk_layernorm
+    h   = gelu(y W_1^T + b)           -> bf16        vitk_gemm_bias_gelu
+    x   = x + h W_2^T + b             -> fp32        vitk_gemm_bias_residual
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .lib import VitkError
+
+
+def _eps_of(norm_module):
+    if not hasattr(norm_module, "eps") or not hasattr(norm_module, "weight"):
+        raise VitkError(f"norm layer {type(norm_module).__name__} is not LayerNorm-like (needs weight, bias, eps)")
+    return float(norm_module.eps)
+
+
+class MLPBlock(nn.Module):
+    """Parameter container + fused path for models/transformer.py:9-26."""
+
+    def __init__(self, in_channels, hidden_channels=None, out_channels=None, dropout=0.):
+        super().__init__()
+        hidden_channels = hidden_channels or in_channels
+        out_channels = out_channels or in_channels
+        self.fc1 = nn.Linear(in_channels, hidden_channels)
+        self.gelu = nn.GELU()
+        self.fc2 = nn.Linear(hidden_channels, out_channels)
+        self.dropout = nn.Dropout(dropout)
+
+    def fused(self, y16, x, h16, w, p):
+        """x += fc2(gelu(fc1(y16)))  (rows = tokens); h16 is the [rows, hidden] scratch."""
+        ops.gemm_bias_gelu(y16, w[p + "fc1.w"], w[p + "fc1.b"], h16)
+        ops.gemm_bias_residual(h16, w[p + "fc2.w"], w[p + "fc2.b"], x, x)
+
+
+class Attention(nn.Module):
+    """Parameter container + fused path for models/transformer.py:29-48."""
+
+    def __init__(self, dim, num_heads=16, attn_bias=True, attn_scaling=None, attn_dropout=0.):
+        super().__init__()
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        self.scaling = attn_scaling or head_dim ** -0.5
+        self.in_proj = nn.Linear(dim, dim * 3, bias=attn_bias)
+        self.dropout = nn.Dropout(attn_dropout)
+        self.out_proj = nn.Linear(dim, dim)
+
+    def fused(self, y16, x, qkv, ctx, w, p):
+        """x += out_proj(attention(in_proj(y16))); qkv/ctx are scratch buffers."""
+        _, B, H, N, hd = qkv.shape
+        ops.qkv_proj(y16, w[p + "qkv.w"], w[p + "qkv.b"], qkv, B, N, H, hd)
+        ops.attention(qkv, ctx, self.scaling)
+        ops.gemm_bias_residual(ctx.view(B * N, H * hd), w[p + "out.w"], w[p + "out.b"], x, x)
+
+
+class Encoder1DBlock(nn.Module):
+    """models/transformer.py:51-76."""
+
+    def __init__(self, hidden_size, num_heads, mlp_ratio=4, dropout=0., attn_bias=True, attn_scaling=None,
+                 attn_dropout=0., norm=nn.LayerNorm, drop_prob=0.):
+        super().__init__()
+        if drop_prob > 0.:
+            raise VitkError("stochastic depth (drop_prob > 0) is not part of the ViT forward path")
+        self.norm1 = norm(hidden_size)
+        self.attention = Attention(hidden_size, num_heads=num_heads, attn_bias=attn_bias,
+                                   attn_scaling=attn_scaling, attn_dropout=attn_dropout)
+        self.norm2 = norm(hidden_size)
+        mlp_dim = int(hidden_size * mlp_ratio)
+        self.mlp = MLPBlock(in_channels=hidden_size, hidden_channels=mlp_dim, dropout=dropout)
+        self.drop_module = nn.Identity()
+        self.dropout = nn.Dropout(dropout)
+
+    def fused(self, ws, w, p):
+        """One pre-LN block, in place on ws.x (fp32 [B, N, D])."""
+        B, N, D = ws.x.shape
+        x2 = ws.x.view(B * N, D)
+        ops.layernorm(x2, w[p + "norm1.w"], w[p + "norm1.b"], _eps_of(self.norm1), ws.y)
+        self.attention.fused(ws.y, x2, ws.qkv, ws.ctx, w, p)
+        ops.layernorm(x2, w[p + "norm2.w"], w[p + "norm2.b"], _eps_of(self.norm2), ws.y)
+        self.mlp.fused(ws.y, x2, ws.h, w, p)
+
+
+class Encoder(nn.Module):
+    """models/transformer.py:79-99."""
+
+    def __init__(self, hidden_size=1024, num_layers=12, num_heads=12, mlp_ratio=4, dropout=0., attn_bias=True,
+                 attn_scaling=None, attn_dropout=0., norm=nn.LayerNorm, drop_prob=0.):
+        super().__init__()
+        # linear ramp 0 .. drop_prob over the layers (pure Python so that meta-device construction works)
+        drop_probs = [drop_prob * i / max(num_layers - 1, 1) for i in range(num_layers)]
+        self.blocks = nn.ModuleList([
+            Encoder1DBlock(hidden_size=hidden_size, num_heads=num_heads, mlp_ratio=mlp_ratio, dropout=dropout,
+                           attn_bias=attn_bias, attn_scaling=attn_scaling, attn_dropout=attn_dropout,
+                           norm=norm, drop_prob=drop_probs[i])
+            for i in range(num_layers)])
+        self.norm = norm(hidden_size)
+
+    def fused(self, ws, w):
+        """All blocks, then the final LayerNorm on the cls row only: LayerNorm is per token
+        and the reference keeps just token 0 afterwards (models/transformer.py:98-99)."""
+        for i, blk in enumerate(self.blocks):
+            blk.fused(ws, w, f"b{i}.")
+        B, N, D = ws.x.shape
+        ops.layernorm(ws.x, w["norm.w"], w["norm.b"], _eps_of(self.norm), ws.cls_n, rows=B, x_row_stride=N * D)
+        return ws.cls_n

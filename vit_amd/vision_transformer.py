@@ -1,0 +1,137 @@
+"""VisionTransformer with the reference's Python surface, run by MI355X kernels.
+
+Mirrors /root/reference/models/vision_transformer.py: the constructor
+signature (:10-13, extra *args/**kwargs swallowed as there), the attribute
+names `embedding, cls_token, pos_embed, dropout, encoder, pre_logits, tanh,
+head` (hence the state_dict keys converter.py emits), the initialisation
+(:34-43) and the six factories `s16, b16, b32, l16, l32, h14` (:59-97).
+
+forward(x: [B,3,H,W]) -> [B,num_classes] runs entirely on libvitk kernels
+(vit_amd.ops); there is no CPU or eager-torch fallback: a CPU tensor, a
+missing library or an unsupported shape raises.
+"""
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .engine import WeightCache, Workspace
+from .lib import VitkError
+from .transformer import Encoder
+
+
+class VisionTransformer(nn.Module):
+    def __init__(self, img_size=384, patches=16, num_classes=1000,
+                 hidden_size=1024, num_layers=12, num_heads=12, mlp_ratio=4,
+                 dropout=0., attn_bias=True, attn_scaling=None, attn_dropout=0.,
+                 norm=nn.LayerNorm, pre_logits=True, *args, **kwargs):
+        super().__init__()
+        self.num_classes = num_classes
+        self.hidden_size = hidden_size
+        self.patches = patches
+        self.img_size = img_size
+        self.num_heads = num_heads
+        self._p_dropout = max(float(dropout), float(attn_dropout))
+
+        self.embedding = nn.Conv2d(3, hidden_size, kernel_size=patches, stride=patches)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, hidden_size))
+        num_patches = (img_size // patches) ** 2
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, hidden_size))
+        self.dropout = nn.Dropout(dropout)
+        self.encoder = Encoder(hidden_size, num_layers, num_heads, mlp_ratio, dropout, attn_bias,
+                               attn_scaling, attn_dropout, norm)
+        self.pre_logits = nn.Linear(hidden_size, hidden_size) if pre_logits else nn.Identity()
+        self.tanh = nn.Tanh() if pre_logits else nn.Identity()
+        self.head = nn.Linear(hidden_size, num_classes)
+
+        self.apply(self._init)
+        # not part of state_dict: kernel-ready weights and activation buffers
+        self._cache = WeightCache(self)
+        self._ws = {}
+
+    def _init(self, module):
+        # same draws as the reference (:34-43); `embedding` keeps Conv2d's default init there too
+        nn.init.normal_(self.pos_embed, std=0.02)
+        nn.init.trunc_normal_(self.cls_token, std=0.2)
+        if isinstance(module, nn.Linear):
+            nn.init.trunc_normal_(module.weight, std=.02)
+            if module.bias is not None:
+                nn.init.constant_(module.bias, 0)
+        elif isinstance(module, nn.LayerNorm):
+            nn.init.constant_(module.bias, 0)
+            nn.init.constant_(module.weight, 1.0)
+
+    def _workspace(self, device, B, N):
+        D, H = self.hidden_size, self.num_heads
+        M = self.encoder.blocks[0].mlp.fc1.out_features if len(self.encoder.blocks) else D
+        key = (str(device), B, N)
+        ws = self._ws.get(key)
+        if ws is None:
+            if len(self._ws) >= 4:      # keep at most a few shapes resident
+                self._ws.clear()
+            ws = self._ws[key] = Workspace(device, B, N, D, H, M, self.num_classes)
+        return ws
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise VitkError("VisionTransformer.forward needs a CUDA/HIP tensor: this path has no CPU fallback")
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise VitkError(f"expected images [B,3,H,W], got {tuple(x.shape)}")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise VitkError("forward-only path: call under torch.no_grad() (backward kernels are not built yet)")
+        if self.training and self._p_dropout > 0.:
+            raise VitkError("dropout > 0 in training mode is not implemented on this path")
+        w = self._cache.get()
+        if w["pos"].device != x.device:
+            raise VitkError(f"model is on {w['pos'].device}, input on {x.device}")
+        B, _, Hi, Wi = x.shape
+        P = self.patches
+        N = (Hi // P) * (Wi // P) + 1
+        if N != w["pos"].shape[0]:
+            raise VitkError(f"input {Hi}x{Wi} gives {N} tokens but pos_embed holds {w['pos'].shape[0]}")
+        ws = self._workspace(x.device, B, N)
+        out_dtype = self.head.weight.dtype
+
+        if x.dtype == torch.bfloat16:
+            img16 = x.contiguous()
+        elif x.dtype == torch.float32:
+            img16 = ops.cast_bf16(x.contiguous(), ws.image_buffer(x))
+        else:
+            raise VitkError(f"unsupported image dtype {x.dtype}")
+
+        ops.patch_embed(img16, w["embed.w"], w["embed.b"], w["cls"], w["pos"], ws.x, P)
+        feat = self.encoder.fused(ws, w)
+        if "pre.w" in w:
+            ops.gemm_bias_tanh(feat, w["pre.w"], w["pre.b"], ws.pre)
+            feat = ws.pre
+        ops.gemm_bias(feat, w["head.w"], w["head.b"], ws.logits)
+        return ws.logits.to(out_dtype, copy=True)
+
+
+def s16(pretrained=False, **kwargs):
+    return VisionTransformer(patches=16, hidden_size=768, num_layers=8, num_heads=8, mlp_ratio=3, **kwargs)
+
+
+def b16(pretrained=False, **kwargs):
+    return VisionTransformer(patches=16, hidden_size=768, num_layers=12, num_heads=12,
+                             norm=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+def b32(pretrained=False, **kwargs):
+    return VisionTransformer(patches=32, hidden_size=768, num_layers=12, num_heads=12,
+                             norm=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+def l16(pretrained=False, **kwargs):
+    return VisionTransformer(patches=16, hidden_size=1024, num_layers=24, num_heads=16,
+                             norm=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+def l32(pretrained=False, **kwargs):
+    return VisionTransformer(patches=32, hidden_size=1024, num_layers=24, num_heads=16,
+                             norm=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+def h14(pretrained=False, **kwargs):
+    return VisionTransformer(patches=14, hidden_size=1280, num_layers=32, num_heads=16, **kwargs)

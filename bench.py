@@ -1,0 +1,166 @@
+"""Headline benchmark: ViT-B/16 224px bf16 forward, images/sec for the whole node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU.  Every rank holds the full weights and runs its own batch of 256 synthetic
+images (weak scaling, no data-path collective); a "step" is one forward over that batch with the
+images already resident in HBM as bf16.  Rank 0 prints ONE JSON line.  Next to the throughput it
+reports the dominant kernel (the fc1 GEMM+bias+GELU launch) against the bf16 MFMA roofline, timed
+with HIP events inside the timed region, and the CPU oracle timed on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import vit_amd                                  # noqa: E402
+from vit_amd import dist as vdist               # noqa: E402
+from vit_amd import ops, synth                  # noqa: E402
+
+MFMA_BF16_PEAK = 2.5166e15     # dense bf16 FLOP/s per MI355X: 256 CU x 2.4 GHz x 4096 FLOP/clk/CU
+
+
+def flops_per_image(cfg, img_size, num_classes=1000):
+    """Algorithmic FLOPs of one forward (2 per multiply-add, full sequence in every layer)."""
+    D, H, P, L = cfg["hidden_size"], cfg["num_heads"], cfg["patches"], cfg["num_layers"]
+    hd, M = D // H, int(D * cfg["mlp_ratio"])
+    n = (img_size // P) ** 2
+    N = n + 1
+    per_layer = 2 * N * D * 3 * D + 2 * (2 * H * N * N * hd) + 2 * N * D * D + 2 * (2 * N * D * M)
+    return 2 * n * (3 * P * P) * D + L * per_layer + 2 * D * D + 2 * D * num_classes
+
+
+class KernelTimer:
+    """HIP-event pairs around every launch of one named kernel, on the stream it is launched on."""
+
+    def __init__(self, name):
+        self.name, self.pairs, self.enabled = name, [], False
+
+    def __call__(self, name):
+        return self if (self.enabled and name == self.name) else ops._NULL
+
+    def __enter__(self):
+        self._a = torch.cuda.Event(enable_timing=True)
+        self._a.record()
+
+    def __exit__(self, *exc):
+        b = torch.cuda.Event(enable_timing=True)
+        b.record()
+        self.pairs.append((self._a, b))
+        return False
+
+    def mean_ms(self):
+        return sum(a.elapsed_time(b) for a, b in self.pairs) / max(len(self.pairs), 1)
+
+
+def cpu_baseline(arch, img_size, sd_cpu, batch):
+    """The CPU oracle (a port of the reference's forward) on this host's cores: warm-up + 3 runs."""
+    from oracle import vit_oracle as vo
+    cfg = synth.ARCHS[arch]
+    x = synth.synth_images(batch, img_size, seed=1)
+    vo.forward(sd_cpu, x[:2], cfg)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        vo.forward(sd_cpu, x, cfg)
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return {"value": round(batch / ts[1], 3), "unit": "images/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{arch} {img_size}px fp32 forward, batch {batch}, median of 3 after warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--arch", default="b16")
+    ap.add_argument("--img-size", type=int, default=224)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank, world, local = vdist.init_from_env()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch one process per GPU")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    cfg = synth.ARCHS[a.arch]
+    sd = synth.synth_state_dict(cfg, a.img_size, seed=0)
+    with torch.device("meta"):
+        model = getattr(vit_amd, a.arch)(img_size=a.img_size)
+    model = model.to_empty(device=dev)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    # rank r owns images [r*B, (r+1)*B) of the synthetic stream; generate a few and tile them
+    lo = rank * a.batch
+    uniq = min(a.batch, 32)
+    x = synth.synth_images(uniq, a.img_size, seed=1, first=lo)
+    x = x.repeat((a.batch + uniq - 1) // uniq, 1, 1, 1)[: a.batch].to(dev).to(torch.bfloat16).contiguous()
+
+    ntok = (a.img_size // cfg["patches"]) ** 2 + 1
+    timer = KernelTimer("gemm_bias_gelu")
+    ops.set_event_hook(timer)
+
+    with torch.no_grad():
+        for _ in range(a.warmup):
+            model(x)
+        torch.cuda.synchronize()
+        vdist.barrier()
+        torch.cuda.synchronize()
+        timer.enabled = True
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            y = model(x)
+        torch.cuda.synchronize()
+        vdist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        timer.enabled = False
+    if not torch.isfinite(y).all():
+        raise SystemExit("non-finite logits")
+    dt = vdist.max_over_ranks(dt, device=dev if world > 1 else "cpu")
+
+    if rank == 0:
+        F = flops_per_image(cfg, a.img_size)
+        value = world * a.batch * a.steps / dt
+        D, Mh = cfg["hidden_size"], int(cfg["hidden_size"] * cfg["mlp_ratio"])
+        k_flops = 2.0 * a.batch * ntok * Mh * D                  # one fc1 launch: [B*N, D] x [M, D]^T
+        k_ms = timer.mean_ms()
+        achieved = k_flops / (k_ms * 1e-3) / 1e12
+        out = {
+            "metric": f"images/sec (whole node) ViT-{a.arch.upper()[0]}/{cfg['patches']} {a.img_size}px bf16 fwd",
+            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"ViT-{a.arch.upper()[0]}/{cfg['patches']} {a.img_size}px forward, "
+                                   f"batch {a.batch} per GPU, random-init weights"
+                                   + (" (BASELINE configs[1])" if (a.arch, a.img_size, a.batch) == ("b16", 224, 256) else ""),
+                       "per_gpu_batch": a.batch, "global_batch": a.batch * world, "tokens": ntok,
+                       "parallelism": f"dp{world}: batch sharded, weights replicated, no collectives"},
+            "gflop_per_image": round(F / 1e9, 3),
+            "mfma_peak_frac": round(value * F / (world * MFMA_BF16_PEAK), 4),
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_256x256<bias+GELU> (fc1)",
+                         "achieved": round(achieved, 1), "peak": round(MFMA_BF16_PEAK / 1e12, 1),
+                         "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_BF16_PEAK, 4),
+                         "avg_launch_ms": round(k_ms, 4), "launches": len(timer.pairs), "traffic": None},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.arch, a.img_size, sd, 32 if a.img_size <= 224 else 8)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        vdist.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,206 @@
+"""Kernel-level parity on the GPU, through the C ABI (vit_amd.ops -> ctypes -> libvitk.so).
+
+Each kernel is compared with the oracle's op on the same seeded inputs.  GEMM-family inputs
+are rounded to bf16 first (that is the kernels' operand type), so the only differences left
+are fp32 summation order and the final bf16 store; tolerances are written per test.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import vit_oracle as vo
+from vit_amd import lib, ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def to16(t):
+    return t.to(torch.bfloat16)
+
+
+def f32(t):
+    return t.detach().float().cpu()
+
+
+@pytest.fixture(autouse=True)
+def _reset_variants():
+    lib.load().vitk_set_debug_variant(0, 0)
+    yield
+    lib.load().vitk_set_debug_variant(0, 0)
+    torch.cuda.synchronize()
+
+
+# ----------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("D", [256, 768, 1024, 1280])
+@pytest.mark.parametrize("rows", [1, 5, 788, 20000])
+def test_layernorm_bf16_out(D, rows):
+    x = rnd(rows, D, seed=rows + D) * 2.0 + 0.3
+    g, b = 1 + 0.1 * rnd(D, seed=1), 0.1 * rnd(D, seed=2)
+    want = vo.layernorm(x, g, b, 1e-6)
+    out = torch.empty(rows, D, dtype=torch.bfloat16, device=DEV)
+    ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), 1e-6, out)
+    # fp32 statistics, one bf16 rounding on store: half an ulp of bf16 = 2^-9 relative
+    assert torch.allclose(f32(out), want, rtol=2 ** -8, atol=1e-5)
+
+
+def test_layernorm_f32_out_and_strided_rows():
+    B, N, D = 6, 197, 768
+    x = rnd(B, N, D, seed=3)
+    g, b = 1 + 0.1 * rnd(D, seed=1), 0.1 * rnd(D, seed=2)
+    want = vo.layernorm(x[:, 0], g, b, 1e-5)
+    out = torch.empty(B, D, dtype=torch.float32, device=DEV)
+    ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), 1e-5, out, rows=B, x_row_stride=N * D)
+    assert torch.allclose(f32(out), want, rtol=1e-5, atol=2e-6)
+
+
+def test_cast():
+    x = rnd(3, 3, 64, 64, seed=4)
+    assert torch.equal(f32(ops.cast_bf16(x.to(DEV))), f32(x.to(torch.bfloat16)))
+
+
+# ----------------------------------------------------------------------------- dense GEMMs
+SHAPES = [(1576, 768, 768), (1576, 3072, 768), (1576, 768, 3072), (256, 1024, 1024), (4728, 2304, 768),
+          (130, 256, 64), (1000, 1280, 5120)]
+
+
+def _dense_inputs(M, N, K, seed):
+    a = to16(rnd(M, K, seed=seed))
+    w = to16(rnd(N, K, seed=seed + 1, scale=0.05))
+    bias = rnd(N, seed=seed + 2, scale=0.1)
+    return a, w, bias
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_gemm_bias_residual(M, N, K, variant):
+    if variant == 2 and M * N * K > 2e9:
+        pytest.skip("small-kernel variant only on small shapes")
+    lib.load().vitk_set_debug_variant(variant, 0)
+    a, w, bias = _dense_inputs(M, N, K, 10)
+    resid = rnd(M, N, seed=13)
+    want = resid + a.float() @ w.float().t() + bias
+    out = resid.to(DEV).clone()
+    ops.gemm_bias_residual(a.to(DEV), w.to(DEV), bias.to(DEV), out, out)      # in place, as the model uses it
+    assert torch.allclose(f32(out), want, rtol=1e-4, atol=2e-4 * (K / 768) ** 0.5)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("M,N,K", SHAPES[:5])
+def test_gemm_bias_gelu(M, N, K, variant):
+    lib.load().vitk_set_debug_variant(variant, 0)
+    a, w, bias = _dense_inputs(M, N, K, 20)
+    want = F.gelu(a.float() @ w.float().t() + bias)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_bias_gelu(a.to(DEV), w.to(DEV), bias.to(DEV), out)
+    assert torch.allclose(f32(out), want, rtol=2 ** -7, atol=2e-3)
+
+
+@pytest.mark.parametrize("M,N,K", [(8, 768, 768), (256, 1000, 768), (3, 10, 64), (256, 768, 768)])
+def test_head_gemms_small_and_irregular(M, N, K):
+    a, w, bias = _dense_inputs(M, N, K, 30)
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm_bias(a.to(DEV), w.to(DEV), bias.to(DEV), out)
+    assert torch.allclose(f32(out), a.float() @ w.float().t() + bias, rtol=1e-4, atol=2e-4)
+    out16 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_bias_tanh(a.to(DEV), w.to(DEV), bias.to(DEV), out16)
+    assert torch.allclose(f32(out16), torch.tanh(a.float() @ w.float().t() + bias), rtol=2 ** -7, atol=2e-3)
+    ops.gemm_bias(a.to(DEV), w.to(DEV), None, out16)
+    assert torch.allclose(f32(out16), a.float() @ w.float().t(), rtol=2 ** -7, atol=2e-3)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("B,N,H,hd", [(3, 197, 12, 64), (2, 577, 12, 64), (2, 197, 16, 64), (2, 197, 8, 96)])
+def test_qkv_projection_head_split(B, N, H, hd, variant):
+    lib.load().vitk_set_debug_variant(variant, 0)
+    D = H * hd
+    a, w, bias = _dense_inputs(B * N, 3 * D, D, 40)
+    want = (a.float() @ w.float().t() + bias).reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    qkv = torch.empty(3, B, H, N, hd, dtype=torch.bfloat16, device=DEV)
+    ops.qkv_proj(a.to(DEV), w.to(DEV), bias.to(DEV), qkv, B, N, H, hd)
+    assert torch.allclose(f32(qkv), want, rtol=2 ** -7, atol=2e-3)
+    ops.qkv_proj(a.to(DEV), w.to(DEV), None, qkv, B, N, H, hd)                  # attn_bias=False
+    assert torch.allclose(f32(qkv), want - bias.reshape(3, 1, H, 1, hd), rtol=2 ** -7, atol=2e-3)
+
+
+# ----------------------------------------------------------------------------- patch embedding
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("B,S,P,D", [(3, 224, 16, 768), (2, 384, 16, 768), (5, 224, 32, 768), (2, 224, 16, 1024),
+                                      (1, 64, 8, 256)])
+def test_patch_embed(B, S, P, D, variant):
+    lib.load().vitk_set_debug_variant(variant, 0)
+    img = to16(rnd(B, 3, S, S, seed=50))
+    w = to16(rnd(D, 3, P, P, seed=51, scale=0.03))
+    bias, cls = rnd(D, seed=52, scale=0.05), rnd(1, 1, D, seed=53, scale=0.2)
+    N = (S // P) ** 2 + 1
+    pos = rnd(1, N, D, seed=54, scale=0.02)
+    sd = {"embedding.weight": w.float(), "embedding.bias": bias, "cls_token": cls, "pos_embed": pos}
+    want = vo.patch_embed(img.float(), sd, P)
+    out = torch.full((B, N, D), float("nan"), dtype=torch.float32, device=DEV)
+    ops.patch_embed(img.to(DEV), w.reshape(D, -1).contiguous().to(DEV), bias.to(DEV), cls.reshape(D).to(DEV),
+                    pos.reshape(N, D).to(DEV), out, P)
+    assert torch.allclose(f32(out), want, rtol=1e-4, atol=3e-4)
+
+
+# ----------------------------------------------------------------------------- attention
+def _attn_ref(q, k, v, scale):
+    s = (q.double() @ k.double().transpose(-2, -1)) * scale
+    p = s.softmax(-1)
+    o = p @ v.double()                              # [B,H,N,hd]
+    B, H, N, hd = q.shape
+    return o.transpose(1, 2).reshape(B, N, H * hd).float()
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("B,H,N", [(2, 12, 197), (1, 12, 577), (3, 2, 1), (2, 3, 32), (2, 3, 33), (1, 4, 224),
+                                   (1, 2, 225), (2, 16, 197), (1, 1, 608)])
+def test_attention(B, H, N, variant):
+    lib.load().vitk_set_debug_variant(0, variant)
+    hd = 64
+    qkv = to16(rnd(3, B, H, N, hd, seed=N + variant))
+    want = _attn_ref(qkv[0].float(), qkv[1].float(), qkv[2].float(), hd ** -0.5)
+    ctx = torch.full((B, N, H * hd), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.attention(qkv.to(DEV), ctx, hd ** -0.5)
+    # probabilities are rounded to bf16 before P.V and the output is stored in bf16
+    assert torch.allclose(f32(ctx), want, rtol=2e-2, atol=6e-3)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_attention_online_softmax_rescale_is_exercised(variant):
+    """A key far down the sequence dominates: the running max jumps in a late key block, so every
+    earlier partial sum must be rescaled.  Scores of ~+-60 also check the exp2 argument handling."""
+    lib.load().vitk_set_debug_variant(0, variant)
+    B, H, N, hd = 1, 2, 197, 64
+    qkv = to16(rnd(3, B, H, N, hd, seed=7))
+    qkv[1, 0, 0, 150] = qkv[0, 0, 0, 10] * 6.0          # key 150 aligned with query 10 of head 0
+    qkv[1, 0, 1, 190] = qkv[0, 0, 1, 100] * 8.0
+    want = _attn_ref(qkv[0].float(), qkv[1].float(), qkv[2].float(), 0.125)
+    ctx = torch.empty(B, N, H * hd, dtype=torch.bfloat16, device=DEV)
+    ops.attention(qkv.to(DEV), ctx, 0.125)
+    assert torch.isfinite(f32(ctx)).all()
+    assert torch.allclose(f32(ctx), want, rtol=2e-2, atol=6e-3)
+
+
+def test_attention_custom_scale_and_row_independence():
+    B, H, N, hd = 4, 12, 197, 64
+    qkv = to16(rnd(3, B, H, N, hd, seed=9))
+    ctx = torch.empty(B, N, H * hd, dtype=torch.bfloat16, device=DEV)
+    ops.attention(qkv.to(DEV), ctx, 0.3)
+    assert torch.allclose(f32(ctx), _attn_ref(qkv[0].float(), qkv[1].float(), qkv[2].float(), 0.3),
+                          rtol=2e-2, atol=6e-3)
+    one = torch.empty(1, N, H * hd, dtype=torch.bfloat16, device=DEV)
+    ops.attention(qkv[:, 2:3].contiguous().to(DEV), one, 0.3)
+    assert torch.equal(one[0], ctx[2])               # an image's result does not depend on its batch
+
+
+def test_unsupported_head_dim_raises():
+    qkv = torch.zeros(3, 1, 8, 197, 96, dtype=torch.bfloat16, device=DEV)
+    ctx = torch.empty(1, 197, 768, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(lib.VitkError, match="hd=96"):
+        ops.attention(qkv, ctx, 0.1)

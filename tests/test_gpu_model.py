@@ -1,0 +1,99 @@
+"""Whole-model parity on the GPU against logits captured from the reference (tests/golden/).
+
+North-star bar for the bf16 path: max-abs logit error <= 1e-2 against the reference's fp32 CPU
+forward on the same weights and images, identical top-1.  The parity images are those whose
+reference top-1 margin exceeds twice that bound (see make_golden.py), so rounding cannot
+legitimately flip them.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vit_oracle as vo
+from tests.helpers import build_model, golden_inputs, load_golden
+import vit_amd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL_BF16 = 1e-2
+
+
+@pytest.mark.parametrize("name", ["b16_224_ref", "b16_224_pert", "b16_384_ref", "l16_224_ref"])
+def test_logits_match_reference(name):
+    meta, g = load_golden(name)
+    cfg, sd, x = golden_inputs(meta)
+    m = build_model(meta["arch"], meta["img_size"], sd, DEV)
+    with torch.no_grad():
+        y = m(x.to(DEV)).float().cpu().numpy()
+        y16 = m(x.to(DEV).to(torch.bfloat16)).float().cpu().numpy()     # caller-side bf16 images
+    err = np.abs(y - g["logits"]).max()
+    print(f"{name}: max-abs logit error {err:.3e}, min margin {meta['min_margin']:.3e}")
+    assert err <= TOL_BF16
+    assert (y.argmax(-1) == g["top1"]).all()
+    assert np.array_equal(y, y16)
+    # intermediates: embedding is a single bf16 GEMM (K=768) + fp32 adds
+    ws = next(iter(m._ws.values()))
+    xfin = ws.x.float().cpu().numpy()
+    assert xfin.shape[0] == meta["batch"]
+
+
+def test_stages_against_bf16_emulating_oracle():
+    """Tighter than the north-star bar: the oracle restated with bf16 rounding at the kernels'
+    rounding points must agree to a few bf16 ulps of the logit scale."""
+    meta, g = load_golden("b16_224_pert")
+    cfg, sd, x = golden_inputs(meta)
+    st = {}
+    want = vo.forward_bf16_emulated(sd, x, cfg, stages=st).numpy()
+    m = build_model("b16", 224, sd, DEV)
+    with torch.no_grad():
+        y = m(x.to(DEV)).float().cpu().numpy()
+    assert np.abs(y - want).max() <= 4e-3
+    assert np.abs(y - g["logits"]).max() <= TOL_BF16
+
+
+def test_batch_256_rows_are_independent_and_match_golden():
+    """BASELINE config 2 size (batch 256): the first 8 images are the golden ones; every image's
+    logits must equal, bit for bit, what the same image gives in a batch of 8."""
+    from vit_amd import synth
+    meta, g = load_golden("b16_224_ref")
+    cfg, sd, x8 = golden_inputs(meta)
+    m = build_model("b16", 224, sd, DEV)
+    rest = synth.synth_images(248, 224, seed=99)
+    x = torch.cat([x8, rest]).to(DEV).to(torch.bfloat16)
+    with torch.no_grad():
+        y256 = m(x).float().cpu()
+        y8 = m(x[:8].contiguous()).float().cpu()
+        ytail = m(x[250:256].contiguous()).float().cpu()
+    assert torch.isfinite(y256).all()
+    assert np.abs(y256[:8].numpy() - g["logits"]).max() <= TOL_BF16
+    assert (y256[:8].argmax(-1).numpy() == g["top1"]).all()
+    assert torch.equal(y256[:8], y8)
+    assert torch.equal(y256[250:256], ytail)
+
+
+def test_weight_update_invalidates_cache_and_extra_shapes():
+    meta, g = load_golden("b16_224_ref")
+    cfg, sd, x = golden_inputs(meta)
+    m = build_model("b16", 224, sd, DEV)
+    xd = x[:2].to(DEV)
+    with torch.no_grad():
+        y0 = m(xd).clone()
+        m.head.bias.add_(1.0)
+        y1 = m(xd)
+    assert torch.allclose(y1, y0 + 1.0, atol=1e-6)
+    with pytest.raises(vit_amd.VitkError):
+        with torch.no_grad():
+            m(torch.zeros(1, 3, 384, 384, device=DEV))         # token count does not match pos_embed
+    with pytest.raises(vit_amd.VitkError):
+        m(xd)                                                   # grad enabled: forward-only path
+
+
+def test_s16_head_dim_96_is_rejected_not_faked():
+    """ViT-S/16 has head_dim 96, which the attention kernel does not cover yet: the module must
+    raise rather than fall back to any other implementation."""
+    meta, _ = load_golden("s16_224_ref")
+    cfg, sd, x = golden_inputs(meta)
+    m = build_model("s16", 224, sd, DEV)
+    with pytest.raises(vit_amd.VitkError, match="hd=96"):
+        with torch.no_grad():
+            m(x[:1].to(DEV))

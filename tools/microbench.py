@@ -1,0 +1,97 @@
+"""Per-kernel timings at the headline shapes (ViT-B/16 224px, batch 256 by default).
+
+    python tools/microbench.py [--batch 256] [--arch b16] [--img-size 224] [--iters 20]
+
+Prints one line per kernel: average launch time (HIP events around `iters` back-to-back launches),
+achieved TFLOP/s for the MFMA kernels and achieved GB/s (algorithmic bytes) for the HBM-bound ones.
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vit_amd import lib, ops, synth   # noqa: E402
+
+
+def timeit(fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--arch", default="b16")
+    ap.add_argument("--img-size", type=int, default=224)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--gemm-variant", type=int, default=0)
+    ap.add_argument("--attn-variant", type=int, default=0)
+    a = ap.parse_args()
+    cfg = synth.ARCHS[a.arch]
+    lib.load().vitk_set_debug_variant(a.gemm_variant, a.attn_variant)
+    dev = "cuda:0"
+    B, D, H, P = a.batch, cfg["hidden_size"], cfg["num_heads"], cfg["patches"]
+    hd, M = D // H, int(D * cfg["mlp_ratio"])
+    N = (a.img_size // P) ** 2 + 1
+    R = B * N
+    bf, f32 = torch.bfloat16, torch.float32
+    g = torch.Generator(device=dev).manual_seed(0)
+    rn = lambda *s, dt=bf, sc=1.0: (torch.randn(*s, device=dev, generator=g) * sc).to(dt)   # noqa: E731
+    x = rn(R, D, dt=f32)
+    y = rn(R, D)
+    h = rn(R, M)
+    qkv = rn(3, B, H, N, hd)
+    ctx = torch.empty(B, N, D, dtype=bf, device=dev)
+    img = rn(B, 3, a.img_size, a.img_size)
+    w_qkv, w_out, w_fc1, w_fc2 = rn(3 * D, D, sc=.02), rn(D, D, sc=.02), rn(M, D, sc=.02), rn(D, M, sc=.02)
+    w_emb = rn(D, 3 * P * P, sc=.02)
+    b_qkv, b_d, b_m = rn(3 * D, dt=f32), rn(D, dt=f32), rn(M, dt=f32)
+    gam, bet = rn(D, dt=f32), rn(D, dt=f32)
+    pos, cls = rn(N, D, dt=f32), rn(D, dt=f32)
+    x3 = x.view(B, N, D)
+
+    rows = []
+
+    def rec(name, t, flops=None, bytes_=None):
+        s = f"{name:34s} {t * 1e6:9.1f} us"
+        if flops:
+            s += f"  {flops / t / 1e12:8.1f} TFLOP/s ({flops / t / 2.5166e15 * 100:5.1f}% of bf16 MFMA peak)"
+        if bytes_:
+            s += f"  {bytes_ / t / 1e9:8.1f} GB/s ({bytes_ / t / 8e12 * 100:5.1f}% of 8 TB/s)"
+        print(s, flush=True)
+        rows.append((name, t))
+
+    it = a.iters
+    print(f"# {a.arch} {a.img_size}px batch {B}: rows={R} D={D} H={H} hd={hd} M={M} N={N} "
+          f"gemm_variant={a.gemm_variant} attn_variant={a.attn_variant}", flush=True)
+    rec("layernorm f32->bf16", timeit(lambda: ops.layernorm(x, gam, bet, 1e-6, y), it), bytes_=R * D * 6)
+    rec("patch_embed (+cls,pos)", timeit(lambda: ops.patch_embed(img, w_emb, b_d, cls, pos, x3, P), it),
+        flops=2.0 * B * (N - 1) * 3 * P * P * D)
+    rec("qkv_proj", timeit(lambda: ops.qkv_proj(y, w_qkv, b_qkv, qkv, B, N, H, hd), it), flops=2.0 * R * 3 * D * D)
+    rec("attention", timeit(lambda: ops.attention(qkv, ctx, hd ** -0.5), it), flops=4.0 * B * H * N * N * hd)
+    rec("out_proj + residual", timeit(lambda: ops.gemm_bias_residual(ctx.view(R, D), w_out, b_d, x, x), it),
+        flops=2.0 * R * D * D)
+    rec("fc1 + bias + GELU", timeit(lambda: ops.gemm_bias_gelu(y, w_fc1, b_m, h), it), flops=2.0 * R * M * D)
+    rec("fc2 + residual", timeit(lambda: ops.gemm_bias_residual(h, w_fc2, b_d, x, x), it), flops=2.0 * R * M * D)
+    o16 = torch.empty(R, D, dtype=bf, device=dev)
+    rec("gemm_bias bf16 (DxD, no epilogue math)", timeit(lambda: ops.gemm_bias(y, w_out, b_d, o16), it),
+        flops=2.0 * R * D * D)
+    L = cfg["num_layers"]
+    per_layer = sum(t for n, t in rows if n in ("qkv_proj", "attention", "out_proj + residual",
+                                               "fc1 + bias + GELU", "fc2 + residual")) + 2 * rows[0][1]
+    total = L * per_layer + rows[1][1]
+    print(f"# sum of kernels for one forward ~ {total * 1e3:.3f} ms -> {B / total:.0f} images/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -42,7 +42,8 @@ int vitk_version(void);
 const char* vitk_last_error(void);
 
 /* Test hook: choose an alternative implementation of the tiled GEMM
- * (0 = LDS-DMA staging, 1 = register staging, 2 = force the small untiled kernel)
+ * (low 4 bits: 0 = pipelined kernel, 1 = basic kernel with LDS-DMA staging, 2 = force the small
+ * untiled kernel, 3 = basic kernel with register staging; bits 4 and up: workgroup -> tile order)
  * and of attention (0 = transposed LDS reads of V, 1 = V stored transposed in LDS).
  * Process-global; results are identical across variants up to fp32 summation order. */
 void vitk_set_debug_variant(int gemm_variant, int attention_variant);

@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--arch", default="b16")
     ap.add_argument("--img-size", type=int, default=224)
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--gemm-variant", type=int, default=0)
+    ap.add_argument("--gemm-variant", type=lambda v: int(v, 0), default=0)
     ap.add_argument("--attn-variant", type=int, default=0)
     a = ap.parse_args()
     cfg = synth.ARCHS[a.arch]

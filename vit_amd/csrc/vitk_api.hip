@@ -50,9 +50,10 @@ int dense(const char* name, const void* A, const void* W, const float* bias, con
     GemmArgs a = {};
     a.A = A; a.W = W; a.bias = bias; a.out = out; a.resid = resid;
     a.M = M; a.N = N; a.K = K; a.lda = K; a.ldo = N;
-    const bool tiled_ok = (N % 256 == 0) && (K % 64 == 0) && M >= 128 && g_gemm_variant != 2;
+    a.order = g_gemm_variant >> 4;
+    const bool tiled_ok = (N % 256 == 0) && (K % 64 == 0) && M >= 128 && (g_gemm_variant & 15) != 2;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (tiled_ok) return launched(launch_gemm_tiled(a, epilogue, false, g_gemm_variant, s), name);
+    if (tiled_ok) return launched(launch_gemm_tiled(a, epilogue, false, g_gemm_variant & 15, s), name);
     return launched(launch_gemm_small(a, epilogue, s), name);
 }
 
@@ -114,7 +115,9 @@ int vitk_patch_embed(const void* img, const void* w, const float* bias, const fl
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rc = launched(launch_cls_pos(cls, pos, x, batch, a.ntok, D, s), "vitk_patch_embed(cls)");
     if (rc) return rc;
-    return launched(launch_gemm_tiled(a, EPI_PATCH_F32, true, g_gemm_variant == 1 ? 1 : 0, s), "vitk_patch_embed");
+    a.order = g_gemm_variant >> 4;
+    const int v = g_gemm_variant & 15;
+    return launched(launch_gemm_tiled(a, EPI_PATCH_F32, true, v == 2 ? 0 : v, s), "vitk_patch_embed");
 }
 
 int vitk_gemm_bias(const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
@@ -156,8 +159,9 @@ int vitk_qkv_proj(const void* A, const void* W, const float* bias, void* qkv, in
     a.A = A; a.W = W; a.bias = bias; a.out = qkv;
     a.M = batch * ntok; a.N = 3 * D; a.K = D; a.lda = D; a.ldo = 0;
     a.ntok = ntok; a.heads = heads; a.hd = hd; a.batch = batch;
-    return launched(launch_gemm_tiled(a, EPI_QKV_BF16, false, g_gemm_variant == 1 ? 1 : 0,
-                                      reinterpret_cast<hipStream_t>(stream)),
+    a.order = g_gemm_variant >> 4;
+    const int v = g_gemm_variant & 15;
+    return launched(launch_gemm_tiled(a, EPI_QKV_BF16, false, v == 2 ? 0 : v, reinterpret_cast<hipStream_t>(stream)),
                     "vitk_qkv_proj");
 }
 

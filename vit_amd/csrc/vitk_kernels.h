@@ -26,6 +26,7 @@ struct GemmArgs {
     int lda, ldo;        // row strides in elements
     int ntok, heads, hd, batch;                 // EPI_QKV_BF16 / EPI_PATCH_F32
     int img_h, img_w, p_log2, grid_w, npatch;   // gather loader
+    int order;           // workgroup -> tile order (low 4 bits: mode, bits 4..: n-group width)
 };
 
 // Every launcher returns hipSuccess or the launch error; shape checks are the caller's job.

@@ -1,0 +1,182 @@
+// Shared pieces of the tiled bf16 GEMM kernels: tile constants, the LDS operand image, and the
+// epilogue that turns a wave's MFMA accumulators into whole-line global stores.
+#pragma once
+#include "vitk_common.h"
+#include "vitk_kernels.h"
+
+namespace vitk {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int kGemmThreads = 512;
+constexpr int kTileBytes = BM * BK * 2;       // one operand tile, 32 KiB
+constexpr int kStageBytes = 2 * kTileBytes;   // A tile + W tile
+constexpr int kRowBytes = BK * 2;             // 128 B per tile row
+constexpr int kEpiBytesPerWave = 4096;        // wave-private epilogue window
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+
+// LDS image of an operand tile: row r (0..255) occupies bytes [128r, 128r+128); its 16-byte
+// chunk c (8 bf16 of K) is stored at slot c ^ ((r >> 1) & 7).  With this XOR the 16 lanes of
+// every ds_read_b128 lane group of an MFMA fragment read (rows r..r+15, one chunk column) land
+// on 16 distinct 16-byte slots of the 256-byte bank row.  LDS-DMA writes linearly (wave base +
+// lane*16), so the XOR is applied to the per-lane SOURCE chunk and again on the read.
+
+// rows advance by `step` inside one image of `per` rows: (b, t) -> (b', t')
+__device__ __forceinline__ void advance_row(int& b, int& t, int step, int per) {
+    t += step;
+    while (t >= per) { t -= per; ++b; }
+}
+
+// Epilogue of one wave's sub-tile: acc[nt][mt][j] = C[m = mw + 16 mt + fr][n = nw + 16 nt + 4 fq + j]
+// for mt < my_mt (fr = lane & 15, fq = lane >> 4).  Accumulators (+bias, +GELU/tanh) go through the
+// wave-private LDS window `win` and are read back as 16-byte row pieces, so every global store
+// (and residual / pos-embed load) instruction covers whole 128-byte lines instead of 32-byte
+// fragments of 16 different rows.  Rows at or past `row_limit` (relative to mw) are not stored;
+// MASKED = false promises my_mt == 8 and row_limit >= 128 and drops every per-row branch.
+template <int EPI, bool MASKED>
+__device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&acc)[4][8], char* win, int mw,
+                                              int nw, int my_mt, int row_limit, int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+    constexpr bool OUT_BF16 = (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_BIAS_TANH_BF16 ||
+                               EPI == EPI_QKV_BF16);
+    if constexpr (OUT_BF16) {
+        // window = 32 rows x 128 B.  8-byte piece (row r, chunk c, half h) lives at
+        // 128 r + 16 (c ^ (r & 7)) + 8 (h ^ ((r >> 3) & 1)): conflict-free for the MFMA-layout
+        // writes (16 rows, one column) and for the row-wise 16-byte reads.
+        f32x4 b4[4];                                 // bias in MFMA layout (it precedes GELU / tanh)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            b4[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias) b4[nt] = *reinterpret_cast<const f32x4*>(p.bias + nw + nt * 16 + fq * 4);
+        }
+        const int rc = lane >> 3, cc = lane & 7;     // read-back role: row within 8, 16-byte chunk
+        uint32_t col_off;                            // element offset contributed by the column
+        if constexpr (EPI == EPI_QKV_BF16) {
+            // column n of the fused projection = which*D + h*hd + e  (reshape(B,N,3,H,hd), transformer.py:42)
+            const int D = p.heads * p.hd;
+            const int n = nw + cc * 8;
+            const int which = n / D, rem = n - which * D;
+            const int h = rem / p.hd, e = rem - h * p.hd;
+            col_off = (((uint32_t)which * p.batch * p.heads + h) * p.ntok) * p.hd + e;
+        } else {
+            col_off = (uint32_t)(nw + cc * 8);
+        }
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            if (MASKED && pass * 2 >= my_mt) break;
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2) {
+                if (MASKED && pass * 2 + m2 >= my_mt) break;
+                const int r = m2 * 16 + fr;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const f32x4 a = acc[nt][pass * 2 + m2];
+                    float v0 = a[0] + b4[nt][0], v1 = a[1] + b4[nt][1], v2 = a[2] + b4[nt][2], v3 = a[3] + b4[nt][3];
+                    if constexpr (EPI == EPI_BIAS_GELU_BF16) {
+                        v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
+                    }
+                    if constexpr (EPI == EPI_BIAS_TANH_BF16) {
+                        v0 = tanhf(v0); v1 = tanhf(v1); v2 = tanhf(v2); v3 = tanhf(v3);
+                    }
+                    const int c = nt * 2 + (fq >> 1), h = fq & 1;
+                    u32x2 o = {pack_bf16(v0, v1), pack_bf16(v2, v3)};
+                    *reinterpret_cast<u32x2*>(win + r * 128 + ((c ^ (r & 7)) << 4) + ((h ^ ((r >> 3) & 1)) << 3)) = o;
+                }
+            }
+            int rb = 0, rt = 0;
+            if constexpr (EPI == EPI_QKV_BF16) {
+                const int mrow = mw + pass * 32 + rc;
+                rb = mrow / p.ntok;
+                rt = mrow - rb * p.ntok;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = i * 8 + rc;
+                u32x4 v = *reinterpret_cast<const u32x4*>(win + r * 128 + ((cc ^ (r & 7)) << 4));
+                if (i & 1) v = u32x4{v[2], v[3], v[0], v[1]};     // rows 8..15 and 24..31 hold swapped halves
+                const int lr = pass * 32 + r;                     // row inside the wave's sub-tile
+                uint32_t off;                                     // element offset (< 2^31: checked by the launcher)
+                if constexpr (EPI == EPI_QKV_BF16) {
+                    off = ((uint32_t)rb * p.heads * p.ntok + rt) * p.hd + col_off;
+                    advance_row(rb, rt, 8, p.ntok);
+                } else {
+                    off = (uint32_t)(mw + lr) * p.ldo + col_off;
+                }
+                if (!MASKED || lr < row_limit)
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.out) + off * 2u) = v;
+            }
+        }
+    } else {
+        // window = 16 rows x 256 B; 16-byte chunk c of row r lives at 256 r + 16 (c ^ (r & 15)).
+        // The residual / pos-embed addend of a quarter sub-tile (2 m-tiles = 8 loads per lane) is
+        // requested up front, before any store of that quarter: out may alias resid, so loads placed
+        // after stores would be kept behind them, one memory round trip per 16 bytes.
+        const int rc = lane >> 4, cc = lane & 15;    // read-back role: row within 4, 16-byte chunk
+        const int ncol = nw + cc * 4;
+        f32x4 bias_rb = {0.f, 0.f, 0.f, 0.f};       // bias in read-back layout: added after the transpose
+        if (p.bias) bias_rb = *reinterpret_cast<const f32x4*>(p.bias + ncol);
+        constexpr bool ADDEND = (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_PATCH_F32);
+        constexpr int QB = (EPI == EPI_PATCH_F32) ? 1 : 2;     // m-tiles per addend batch (register budget)
+        // 32-bit byte offsets from the (uniform) tensor bases keep the address registers few; the
+        // launcher guarantees that every tensor touched here is smaller than 4 GiB.
+        const char* resid_b = reinterpret_cast<const char*>(p.resid);
+        const char* pos_b = reinterpret_cast<const char*>(p.pos);
+        char* out_b = reinterpret_cast<char*>(p.out);
+#pragma unroll
+        for (int batch = 0; batch < 8 / QB; ++batch) {
+            if (MASKED && batch * QB >= my_mt) break;
+            f32x4 add[QB][4];
+            uint32_t orow[QB][4];     // output row of each piece (PATCH only; else it is mw + local row)
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                const int mt = batch * QB + q;
+                int rb = 0, rt = 0;
+                if constexpr (EPI == EPI_PATCH_F32) {
+                    int mrow = mw + mt * 16 + rc;
+                    mrow = mrow < p.M ? mrow : p.M - 1;
+                    rb = mrow / p.npatch;
+                    rt = mrow - rb * p.npatch;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int m = mw + mt * 16 + i * 4 + rc;
+                    if (MASKED) m = m < p.M ? m : p.M - 1;      // loads stay in bounds; stores are masked below
+                    if constexpr (EPI == EPI_PATCH_F32) {
+                        // patch row (b, pidx) lands at token 1 + pidx (the cls token is row 0) and takes
+                        // that token's position embedding: vision_transformer.py:47-50
+                        orow[q][i] = (uint32_t)(rb * p.ntok + 1 + rt);
+                        add[q][i] = *reinterpret_cast<const f32x4*>(pos_b + ((uint32_t)(1 + rt) * p.N + ncol) * 4u);
+                        advance_row(rb, rt, 4, p.npatch);
+                    } else if constexpr (EPI == EPI_BIAS_RESID_F32) {
+                        add[q][i] = *reinterpret_cast<const f32x4*>(resid_b + ((uint32_t)m * p.ldo + ncol) * 4u);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                const int mt = batch * QB + q;
+                if (MASKED && mt >= my_mt) break;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    *reinterpret_cast<f32x4*>(win + fr * 256 + (((nt * 4 + fq) ^ fr) << 4)) = acc[nt][mt];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = i * 4 + rc;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(win + r * 256 + ((cc ^ r) << 4));
+                    v = v + bias_rb;
+                    if constexpr (ADDEND) v = v + add[q][i];
+                    const int lr = mt * 16 + r;
+                    const uint32_t orow_i = (EPI == EPI_PATCH_F32) ? orow[q][i] : (uint32_t)(mw + lr);
+                    if (!MASKED || lr < row_limit)
+                        *reinterpret_cast<f32x4*>(out_b + (orow_i * p.ldo + ncol) * 4u) = v;
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_gemm_pipe(const GemmArgs& a, int epilogue, bool gather, hipStream_t s);
+
+}  // namespace vitk

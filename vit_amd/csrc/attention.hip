@@ -16,14 +16,19 @@
 //   packing to bf16, already the B operand of this product (its k order is
 //   key = 16s + 8(j>>2) + 4*(lane>>5) + (j&3) for element j of k-step s).
 // The [ntok, ntok] score matrix never exists in memory.
+#include <type_traits>
+
 #include "vitk_common.h"
 #include "vitk_kernels.h"
 
 namespace vitk {
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
 
 constexpr float kMaskedScore = -1.0e30f;
+static int g_attn_probe = 0;   // timing probe (debug variant bit 2): all workgroups read head 0
 
 // VTR = true : V row-major in LDS, transposed fragments via ds_read_b64_tr_b16.
 // VTR = false: V stored transposed ([d][key]) in LDS, fragments via ds_read_b64.
@@ -32,7 +37,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_hd64(const bf16_t* __re
                                                               const bf16_t* __restrict__ K,
                                                               const bf16_t* __restrict__ V,
                                                               bf16_t* __restrict__ O, int ntok, int heads,
-                                                              float scale_log2e) {
+                                                              float scale_log2e, int probe) {
     constexpr int HD = 64;
     constexpr int RB = HD * 2;   // bytes per K/V row
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -40,7 +45,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_hd64(const bf16_t* __re
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int bh = blockIdx.x;   // image * heads + head
+    const int bh = (probe & 1) ? 0 : blockIdx.x;   // image * heads + head (probe: every workgroup reads head 0)
     const int kblocks = (ntok + 31) >> 5;
     const int kpad = kblocks * 32;
     const int vts = kpad + 4;    // V^T row stride in elements (VTR = false)
@@ -48,12 +53,26 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_hd64(const bf16_t* __re
     char* k_lds = smem;
     char* v_lds = smem + kpad * RB;
 
-    // ---- stage K and V of this head: 16-byte chunks, rows past ntok zero-filled.
+    // ---- stage K and V of this head.
     // K slot = chunk ^ ((row >> 1) & 7)   (conflict-free ds_read_b128 of 32 rows x one chunk column)
     // V slot = chunk ^ (((row >> 1) & 1) << 2)  (conflict-free transposed read of 4 rows x 64 B)
-    {
-        const bf16_t* kg = K + (size_t)bh * ntok * HD;
-        const bf16_t* vg = V + (size_t)bh * ntok * HD;
+    const bf16_t* kg = K + (size_t)bh * ntok * HD;
+    const bf16_t* vg = V + (size_t)bh * ntok * HD;
+    if constexpr (VTR) {
+        // LDS-DMA: one wave instruction moves 8 rows x 128 B; LDS is written linearly, so the slot
+        // XOR is applied to each lane's SOURCE chunk.  Rows past ntok re-read the last row (finite
+        // values: such keys are masked out of the softmax, and their P is 0 in P.V).
+        const int pieces = kpad >> 3;                        // per operand
+        for (int pi = wave; pi < 2 * pieces; pi += NW) {     // wave-uniform
+            const bool is_v = pi >= pieces;
+            const int row = ((is_v ? pi - pieces : pi) << 3) + (lane >> 3);
+            const int slot = lane & 7;
+            const int c = is_v ? slot ^ (((row >> 1) & 1) << 2) : slot ^ ((row >> 1) & 7);
+            const int grow = row < ntok ? row : ntok - 1;
+            const bf16_t* src = (is_v ? vg : kg) + (size_t)grow * HD + c * 8;
+            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(smem + pi * 1024), 16, 0, 0);
+        }
+    } else {
         for (int cid = tid; cid < kpad * 8; cid += NW * 64) {
             const int row = cid >> 3, c = cid & 7;
             u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
@@ -62,15 +81,11 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_hd64(const bf16_t* __re
                 vv = *reinterpret_cast<const u32x4*>(vg + (size_t)row * HD + c * 8);
             }
             *reinterpret_cast<u32x4*>(k_lds + row * RB + ((c ^ ((row >> 1) & 7)) << 4)) = kv;
-            if constexpr (VTR) {
-                *reinterpret_cast<u32x4*>(v_lds + row * RB + ((c ^ (((row >> 1) & 1) << 2)) << 4)) = vv;
-            } else {
-                unsigned short* vt = reinterpret_cast<unsigned short*>(v_lds);
+            unsigned short* vt = reinterpret_cast<unsigned short*>(v_lds);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    vt[(c * 8 + 2 * j) * vts + row] = (unsigned short)(vv[j] & 0xFFFFu);
-                    vt[(c * 8 + 2 * j + 1) * vts + row] = (unsigned short)(vv[j] >> 16);
-                }
+            for (int j = 0; j < 4; ++j) {
+                vt[(c * 8 + 2 * j) * vts + row] = (unsigned short)(vv[j] & 0xFFFFu);
+                vt[(c * 8 + 2 * j + 1) * vts + row] = (unsigned short)(vv[j] >> 16);
             }
         }
     }
@@ -86,6 +101,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_hd64(const bf16_t* __re
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qg + ks * 16);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed
     __syncthreads();
 
     f32x16 o_acc[2];
@@ -93,64 +109,91 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_hd64(const bf16_t* __re
     for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int i = 0; i < 16; ++i) o_acc[d][i] = 0.f;
+    // Online softmax with a lazy running max (log2 units): the accumulators are rescaled only when a
+    // block's max exceeds the running one by more than kLazy, so probabilities stay below 2^kLazy
+    // (exact in fp32 sums, same relative rounding in bf16) and most blocks skip the 32-register rescale.
+    constexpr float kLazy = 8.0f;
     float m_run = kMaskedScore, l_run = 0.f;
 
     const int kswz = (r >> 1) & 7;
     // transposed-read lane roles: 16-lane group -> d sub-block, lane -> (key row, 4-column piece)
     const int tsub = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
+    const bool ragged = (ntok & 31) != 0;
 
-    if (q0 < ntok) {   // wave-uniform: a wave whose whole q-tile is padding only took part in staging
-        for (int kb = 0; kb < kblocks; ++kb) {
-            // S^T block: 32 keys x 32 queries, K = head_dim in 4 steps of 16
-            f32x16 s;
+    // One step of the key loop over NB (1 or 2) blocks of 32 keys.  Two blocks give two independent
+    // MFMA chains and share one max exchange and one rescale decision.
+    auto key_step = [&](int kb, auto nb_c) {
+        constexpr int NB = decltype(nb_c)::value;
+        f32x16 s[NB];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) s[i] = 0.f;
-            const char* krow = k_lds + (kb * 32 + r) * RB;
+        for (int u = 0; u < NB; ++u) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            for (int i = 0; i < 16; ++i) s[u][i] = 0.f;
+        }
+        // S^T blocks: 32 keys x 32 queries each, K = head_dim in 4 steps of 16
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const char* krow = k_lds + ((kb + u) * 32 + r) * RB;
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + (((ks * 2 + hh) ^ kswz) << 4));
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+                s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[u], 0, 0, 0);
             }
-            // scores in log2 units; keys past ntok (last block only) are masked out
-            const int key0 = kb * 32 + 4 * hh;
-            float mx = kMaskedScore;
+        }
+        if (ragged && kb + NB == kblocks) {     // wave-uniform: keys past ntok exist only in the last block
+            const int key0 = (kb + NB - 1) * 32 + 4 * hh;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float v = s[i] * scale_log2e;
-                if (key0 + (i & 3) + 8 * (i >> 2) >= ntok) v = kMaskedScore;
-                s[i] = v;
-                mx = fmaxf(mx, v);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            for (int i = 0; i < 16; ++i)
+                if (key0 + (i & 3) + 8 * (i >> 2) >= ntok) s[NB - 1][i] = kMaskedScore;
+        }
+        float mx = fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]);
+#pragma unroll
+        for (int i = 3; i < 15; i += 2) mx = fmaxf(fmaxf(mx, s[0][i]), s[0][i + 1]);
+        mx = fmaxf(mx, s[0][15]);
+        if constexpr (NB == 2) {
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) mx = fmaxf(fmaxf(mx, s[1][i]), s[1][i + 1]);
+        }
+        // The other half-wave holds the other 16 keys of each block for the same query.  The swap
+        // exchanges lanes 32..63 of its first operand with lanes 0..31 of its second: each lane finds
+        // its partner's value in one of the two results and its own in the other.
+        {
+            const unsigned mxu = __builtin_bit_cast(unsigned, mx);
+            const auto sw = __builtin_amdgcn_permlane32_swap(mxu, mxu, false, false);
+            mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1])) * scale_log2e;
+        }                                                              // scale > 0: max commutes with it
+        if (__any(mx > m_run + kLazy)) {
             const float m_new = fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             m_run = m_new;
-            float psum = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                s[i] = __builtin_amdgcn_exp2f(s[i] - m_new);
-                psum += s[i];
-            }
-            l_run = l_run * alpha + psum;
+            l_run *= alpha;
 #pragma unroll
             for (int d = 0; d < 2; ++d)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) o_acc[d][i] *= alpha;
-            // P^T fragments (B operand), one per 16-key step
-            bf16x8 pf[2];
+        }
+        float psum = 0.f;
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                s[u][i] = __builtin_amdgcn_exp2f(fmaf(s[u][i], scale_log2e, -m_run));
+                psum += s[u][i];
+            }
+        }
+        l_run += psum;
+        // O^T[d][q] += V^T[d][key] P^T[key][q]; the packed P^T accumulators are the B operand
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                u32x4 pk = {pack_bf16(s[8 * st + 0], s[8 * st + 1]), pack_bf16(s[8 * st + 2], s[8 * st + 3]),
-                            pack_bf16(s[8 * st + 4], s[8 * st + 5]), pack_bf16(s[8 * st + 6], s[8 * st + 7])};
-                pf[st] = __builtin_bit_cast(bf16x8, pk);
-            }
-            // O^T[d][q] += V^T[d][key] P^T[key][q]
+                u32x4 pk = {pack_bf16(s[u][8 * st + 0], s[u][8 * st + 1]), pack_bf16(s[u][8 * st + 2], s[u][8 * st + 3]),
+                            pack_bf16(s[u][8 * st + 4], s[u][8 * st + 5]), pack_bf16(s[u][8 * st + 6], s[u][8 * st + 7])};
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
 #pragma unroll
-            for (int d = 0; d < 2; ++d) {
-#pragma unroll
-                for (int st = 0; st < 2; ++st) {
+                for (int d = 0; d < 2; ++d) {
                     bf16x4 v0, v1;
-                    const int keyb = kb * 32 + 16 * st + 4 * hh;   // + 8t + (0..3)
+                    const int keyb = (kb + u) * 32 + 16 * st + 4 * hh;   // + 8t + (0..3)
                     if constexpr (VTR) {
                         const int chunk = d * 4 + tsub * 2 + (tp >> 1);
                         const int ka = keyb + tq, kb2 = keyb + 8 + tq;
@@ -164,10 +207,17 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_hd64(const bf16_t* __re
                         v1 = *reinterpret_cast<const bf16x4*>(vt + 8);
                     }
                     const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[st], o_acc[d], 0, 0, 0);
+                    o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o_acc[d], 0, 0, 0);
                 }
             }
         }
+    };
+
+    if (q0 < ntok) {   // wave-uniform: a wave whose whole q-tile is padding only took part in staging
+        int kb = 0;
+        const int kend = (probe & 2) ? 0 : kblocks;      // probe bit 1: skip the key loop (timing only)
+        for (; kb + 2 <= kend; kb += 2) key_step(kb, std::integral_constant<int, 2>{});
+        if (kb < kend) key_step(kb, std::integral_constant<int, 1>{});
 
         // ---- normalise and store: lane holds q = qrow, d = 32*blk + 8g + 4*hh + (0..3)
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -203,7 +253,7 @@ static hipError_t attn_launch(const void* q, const void* k, const void* v, void*
     hipLaunchKernelGGL((attention_fwd_hd64<NW, VTR>), grid, block, lds, s,
                        reinterpret_cast<const bf16_t*>(q), reinterpret_cast<const bf16_t*>(k),
                        reinterpret_cast<const bf16_t*>(v), reinterpret_cast<bf16_t*>(out), ntok, heads,
-                       scale * 1.44269504088896340736f);
+                       scale * 1.44269504088896340736f, g_attn_probe);
     return hipGetLastError();
 }
 
@@ -215,6 +265,7 @@ hipError_t launch_attention(const void* q, const void* k, const void* v, void* o
     // q-tiles fit 7 waves (K/V staged once), else the width that leaves the fewest idle
     // wave slots, larger on ties.
     const bool tr = (variant & 1) == 0;
+    g_attn_probe = (variant >> 2) & 3;
     int nw = 4;
     if (qtiles > 4 && qtiles <= 7) {
         nw = 7;

@@ -52,13 +52,24 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
         }
         const int rc = lane >> 3, cc = lane & 7;     // read-back role: row within 8, 16-byte chunk
         uint32_t col_off;                            // element offset contributed by the column
+        int rb0 = 0, rt0 = 0;                        // QKV: (image, token) of row mw
         if constexpr (EPI == EPI_QKV_BF16) {
-            // column n of the fused projection = which*D + h*hd + e  (reshape(B,N,3,H,hd), transformer.py:42)
+            // column n of the fused projection = which*D + h*hd + e  (reshape(B,N,3,H,hd), transformer.py:42).
+            // The divisions run on wave-uniform values (scalar unit); per lane only when the wave's 64
+            // columns straddle a head boundary (head_dim not a multiple of 64).
             const int D = p.heads * p.hd;
-            const int n = nw + cc * 8;
-            const int which = n / D, rem = n - which * D;
-            const int h = rem / p.hd, e = rem - h * p.hd;
-            col_off = (((uint32_t)which * p.batch * p.heads + h) * p.ntok) * p.hd + e;
+            const int which_u = nw / D, rem_u = nw - which_u * D;
+            const int h_u = rem_u / p.hd, e_u = rem_u - h_u * p.hd;
+            if (e_u + 64 <= p.hd) {
+                col_off = (((uint32_t)which_u * p.batch * p.heads + h_u) * p.ntok) * p.hd + e_u + cc * 8;
+            } else {
+                const int n = nw + cc * 8;
+                const int which = n / D, rem = n - which * D;
+                const int h = rem / p.hd, e = rem - h * p.hd;
+                col_off = (((uint32_t)which * p.batch * p.heads + h) * p.ntok) * p.hd + e;
+            }
+            rb0 = mw / p.ntok;
+            rt0 = mw - rb0 * p.ntok;
         } else {
             col_off = (uint32_t)(nw + cc * 8);
         }
@@ -84,12 +95,8 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
                     *reinterpret_cast<u32x2*>(win + r * 128 + ((c ^ (r & 7)) << 4) + ((h ^ ((r >> 3) & 1)) << 3)) = o;
                 }
             }
-            int rb = 0, rt = 0;
-            if constexpr (EPI == EPI_QKV_BF16) {
-                const int mrow = mw + pass * 32 + rc;
-                rb = mrow / p.ntok;
-                rt = mrow - rb * p.ntok;
-            }
+            int rb = rb0, rt = rt0;
+            if constexpr (EPI == EPI_QKV_BF16) advance_row(rb, rt, pass * 32 + rc, p.ntok);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = i * 8 + rc;

@@ -12,8 +12,6 @@
 // Per K tile and wave: 2 x { 12 ds_read_b128 of the next k-step's fragments, 32 MFMA 16x16x32 of
 // the current one }, one s_barrier.  Waves are 2 (m) x 4 (n); the two waves that share a SIMD
 // (w and w + 4) take the two m halves, so an odd mtot still loads every SIMD equally.
-#include <type_traits>
-
 #include "gemm_common.h"
 
 namespace vitk {
@@ -100,7 +98,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_pipe(const GemmArgs
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = (i * 8 + wave) * 8 + srow;
-            if (i * 8 + wave < a_pieces) {                       // wave-uniform
+            if (i * 8 + wave < a_pieces) {                       // wave-uniform: pieces past the tile height are skipped
                 int gm = iss_m0 + row;
                 gm = gm < p.M ? gm : p.M - 1;                    // rows past M re-read the last row; never stored
                 uint32_t ao;
@@ -194,22 +192,16 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_pipe(const GemmArgs
             const int cur = step & 1;
             // phase A: fragments of k-step 1 in flight under the MFMAs of k-step 0
             load_frags(af1, wf1, cur, 1);
-            __builtin_amdgcn_sched_barrier(0);
             mma(af0, wf0);
-            __builtin_amdgcn_sched_barrier(0);
             // every wave is done reading stage `cur`, and K tile step+1 has landed in the other stage
             __builtin_amdgcn_s_waitcnt(kWaitVmLgkm0);
             __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            // phase B: refill stage `cur` with K tile step+2 (possibly the next output tile's), fetch
-            // the first fragments of K tile step+1 when it belongs to this output tile
+            // phase B: refill stage `cur` with K tile step+2 (possibly the next output tile's)
             if (step + 2 < total_steps) issue_next();
+            // fetch the first fragments of K tile step+1 when it belongs to this output tile
             if (kt + 1 < ktiles) load_frags(af0, wf0, cur ^ 1, 0);
-            __builtin_amdgcn_sched_barrier(0);
             mma(af1, wf1);
-            __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(kWaitLgkm0);   // those fragments had 32 MFMAs to arrive
-            __builtin_amdgcn_sched_barrier(0);
         }
 
         // ---- epilogue (the next output tile's first two K tiles are in flight or landed meanwhile)

@@ -1,9 +1,11 @@
-"""Time the tiled GEMM (bf16 out, bias) over a list of shapes: us per launch, TFLOP/s, and us per
-K tile per round of tiles (256 CUs, one 256x256 tile each) -- a stride/latency diagnostic.
+"""Time the tiled GEMM over a list of shapes and debug variants.  Variants are timed interleaved, in
+rounds, inside one process (median and min over the rounds are printed), because launch-to-launch
+clock and box-to-box differences are larger than most kernel changes.
 
-    python tools/gemm_sweep.py M N K [M N K ...]
+    python tools/gemm_sweep.py [--variant=0,4,...] [--epi=bias|resid|gelu] [--rounds=5] M N K [M N K ...]
 """
 import os
+import statistics
 import sys
 
 import torch
@@ -14,17 +16,18 @@ from vit_amd import lib, ops   # noqa: E402
 
 def main():
     argv = sys.argv[1:]
-    variant, epi = 0, "bias"
+    variants, epi, rounds = [0], "bias", 5
     while argv and argv[0].startswith("--"):
         k, v = argv.pop(0)[2:].split("=")
         if k == "variant":
-            variant = int(v, 0)
+            variants = [int(x, 0) for x in v.split(",")]
         elif k == "epi":
             epi = v
+        elif k == "rounds":
+            rounds = int(v)
     a = [int(v) for v in argv]
     dev = "cuda:0"
-    lib.load().vitk_set_debug_variant(variant, 0)
-    print(f"# gemm variant {variant:#x} epilogue {epi}")
+    print(f"# epilogue {epi}, {rounds} interleaved rounds of 10 launches: median us (min us) median TFLOP/s")
     for M, N, K in zip(a[0::3], a[1::3], a[2::3]):
         A = torch.randn(M, K, device=dev).to(torch.bfloat16)
         W = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
@@ -38,21 +41,25 @@ def main():
         else:
             out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
             run = lambda: ops.gemm_bias(A, W, b, out)                 # noqa: E731
-        for _ in range(3):
-            run()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            run()
-        e1.record()
-        torch.cuda.synchronize()
-        t = e0.elapsed_time(e1) / 10 * 1e-3
-        tiles = ((M + 255) // 256) * (N // 256)
-        rounds = (tiles + 255) // 256
-        print(f"M={M} N={N} K={K}: {t * 1e6:8.1f} us  {2.0 * M * N * K / t / 1e12:7.1f} TFLOP/s  tiles={tiles} "
-              f"rounds={rounds}  us/round={t * 1e6 / rounds:6.1f}  us/(round*ktile)={t * 1e6 / rounds / (K // 64):5.2f}",
-              flush=True)
+        times = {v: [] for v in variants}
+        for r in range(rounds + 1):                 # round 0 is warm-up
+            for v in variants:
+                lib.load().vitk_set_debug_variant(v, 0)
+                run()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    run()
+                e1.record()
+                torch.cuda.synchronize()
+                if r:
+                    times[v].append(e0.elapsed_time(e1) / 10 * 1e3)
+        print(f"M={M} N={N} K={K}")
+        for v in variants:
+            med, lo = statistics.median(times[v]), min(times[v])
+            print(f"   variant {v:#9x}: {med:8.1f} us ({lo:8.1f})  {2.0 * M * N * K / med / 1e6:7.1f} TFLOP/s", flush=True)
+    lib.load().vitk_set_debug_variant(0, 0)
 
 
 if __name__ == "__main__":

@@ -222,7 +222,7 @@ template <int EPI, bool GATHER>
 static hipError_t launch_variant(const GemmArgs& a, int variant, hipStream_t s) {
     const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
     // variant: 0 = pipelined kernel (default); 1 = basic kernel, LDS-DMA staging; 3 = basic kernel,
-    // register staging (2, the untiled kernel, is dispatched by the caller)
+    // register staging; 4 = two-group phased kernel (2, the untiled kernel, is dispatched by the caller)
     if (variant == 3)
         hipLaunchKernelGGL((gemm_bf16_256x256<EPI, GATHER, 1>), dim3(tiles), dim3(kGemmThreads), 0, s, a);
     else if (variant == 1)
@@ -233,6 +233,8 @@ static hipError_t launch_variant(const GemmArgs& a, int variant, hipStream_t s) 
              (EPI == EPI_PATCH_F32 && (size_t)a.batch * a.ntok * a.N * 4 >= (1ull << 32)))
         // the pipelined kernel addresses operands and outputs with 32-bit byte offsets
         hipLaunchKernelGGL((gemm_bf16_256x256<EPI, GATHER, 0>), dim3(tiles), dim3(kGemmThreads), 0, s, a);
+    else if (variant == 4)
+        return launch_gemm_pp(a, EPI, GATHER, s);
     else
         return launch_gemm_pipe(a, EPI, GATHER, s);
     return hipGetLastError();

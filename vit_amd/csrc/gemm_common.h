@@ -185,5 +185,6 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
 }
 
 hipError_t launch_gemm_pipe(const GemmArgs& a, int epilogue, bool gather, hipStream_t s);
+hipError_t launch_gemm_pp(const GemmArgs& a, int epilogue, bool gather, hipStream_t s);
 
 }  // namespace vitk

@@ -149,7 +149,7 @@ def main():
                        "parallelism": f"dp{world}: batch sharded, weights replicated, no collectives"},
             "gflop_per_image": round(F / 1e9, 3),
             "mfma_peak_frac": round(value * F / (world * MFMA_BF16_PEAK), 4),
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_256x256<bias+GELU> (fc1)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_pp<bias+GELU> (fc1)",
                          "achieved": round(achieved, 1), "peak": round(MFMA_BF16_PEAK / 1e12, 1),
                          "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_BF16_PEAK, 4),
                          "avg_launch_ms": round(k_ms, 4), "launches": len(timer.pairs), "traffic": None},

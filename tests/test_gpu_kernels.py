@@ -67,7 +67,7 @@ def test_cast():
 
 # ----------------------------------------------------------------------------- dense GEMMs
 SHAPES = [(1576, 768, 768), (1576, 3072, 768), (1576, 768, 3072), (256, 1024, 1024), (4728, 2304, 768),
-          (130, 256, 64), (1000, 1280, 5120)]
+          (130, 256, 64), (1000, 1280, 5120), (8200, 2304, 768), (300, 512, 128), (300, 512, 192)]
 
 
 def _dense_inputs(M, N, K, seed):
@@ -77,7 +77,7 @@ def _dense_inputs(M, N, K, seed):
     return a, w, bias
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 0x43, 0x13, 0xa04])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5, 0x43, 0x13, 0xa00, 0x45, 0xa05])
 @pytest.mark.parametrize("M,N,K", SHAPES)
 def test_gemm_bias_residual(M, N, K, variant):
     if (variant & 15) == 2 and M * N * K > 2e9:
@@ -91,7 +91,7 @@ def test_gemm_bias_residual(M, N, K, variant):
     assert torch.allclose(f32(out), want, rtol=1e-4, atol=2e-4 * (K / 768) ** 0.5)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 4])
+@pytest.mark.parametrize("variant", [0, 1, 5])
 @pytest.mark.parametrize("M,N,K", SHAPES[:5])
 def test_gemm_bias_gelu(M, N, K, variant):
     lib.load().vitk_set_debug_variant(variant, 0)
@@ -115,7 +115,7 @@ def test_head_gemms_small_and_irregular(M, N, K):
     assert torch.allclose(f32(out16), a.float() @ w.float().t(), rtol=2 ** -7, atol=2e-3)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 4, 0x33])
+@pytest.mark.parametrize("variant", [0, 1, 5, 0x33, 0x35])
 @pytest.mark.parametrize("B,N,H,hd", [(3, 197, 12, 64), (2, 577, 12, 64), (2, 197, 16, 64), (2, 197, 8, 96)])
 def test_qkv_projection_head_split(B, N, H, hd, variant):
     lib.load().vitk_set_debug_variant(variant, 0)
@@ -130,7 +130,7 @@ def test_qkv_projection_head_split(B, N, H, hd, variant):
 
 
 # ----------------------------------------------------------------------------- patch embedding
-@pytest.mark.parametrize("variant", [0, 1, 4])
+@pytest.mark.parametrize("variant", [0, 1, 5])
 @pytest.mark.parametrize("B,S,P,D", [(3, 224, 16, 768), (2, 384, 16, 768), (5, 224, 32, 768), (2, 224, 16, 1024),
                                       (1, 64, 8, 256)])
 def test_patch_embed(B, S, P, D, variant):
@@ -157,7 +157,7 @@ def _attn_ref(q, k, v, scale):
     return o.transpose(1, 2).reshape(B, N, H * hd).float()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 4])
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("B,H,N", [(2, 12, 197), (1, 12, 577), (3, 2, 1), (2, 3, 32), (2, 3, 33), (1, 4, 224),
                                    (1, 2, 225), (2, 16, 197), (1, 1, 608)])
 def test_attention(B, H, N, variant):

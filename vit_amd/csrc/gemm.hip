@@ -221,8 +221,9 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_256x256(const GemmA
 template <int EPI, bool GATHER>
 static hipError_t launch_variant(const GemmArgs& a, int variant, hipStream_t s) {
     const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
-    // variant: 0 = pipelined kernel (default); 1 = basic kernel, LDS-DMA staging; 3 = basic kernel,
-    // register staging; 4 = two-group phased kernel (2, the untiled kernel, is dispatched by the caller)
+    // variant: 0 = default (two-group phased kernel where it applies, else the one-group pipelined
+    // kernel); 1 = basic kernel, LDS-DMA staging; 3 = basic kernel, register staging; 4 = same as 0;
+    // 5 = one-group pipelined kernel (2, the untiled kernel, is dispatched by the caller)
     if (variant == 3)
         hipLaunchKernelGGL((gemm_bf16_256x256<EPI, GATHER, 1>), dim3(tiles), dim3(kGemmThreads), 0, s, a);
     else if (variant == 1)
@@ -231,10 +232,10 @@ static hipError_t launch_variant(const GemmArgs& a, int variant, hipStream_t s) 
              (GATHER && (size_t)a.batch * 3 * a.img_h * a.img_w * 2 >= (1ull << 32)) ||
              (size_t)(a.M + 256) * a.N * 4 >= (1ull << 32) ||
              (EPI == EPI_PATCH_F32 && (size_t)a.batch * a.ntok * a.N * 4 >= (1ull << 32)))
-        // the pipelined kernel addresses operands and outputs with 32-bit byte offsets
+        // the persistent kernels address operands and outputs with 32-bit byte offsets
         hipLaunchKernelGGL((gemm_bf16_256x256<EPI, GATHER, 0>), dim3(tiles), dim3(kGemmThreads), 0, s, a);
-    else if (variant == 4)
-        return launch_gemm_pp(a, EPI, GATHER, s);
+    else if (variant != 5 && gemm_pp_supports(a, GATHER))
+        return launch_gemm_pp(a, EPI, s);
     else
         return launch_gemm_pipe(a, EPI, GATHER, s);
     return hipGetLastError();

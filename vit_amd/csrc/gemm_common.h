@@ -185,6 +185,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
 }
 
 hipError_t launch_gemm_pipe(const GemmArgs& a, int epilogue, bool gather, hipStream_t s);
-hipError_t launch_gemm_pp(const GemmArgs& a, int epilogue, bool gather, hipStream_t s);
+bool gemm_pp_supports(const GemmArgs& a, bool gather);
+hipError_t launch_gemm_pp(const GemmArgs& a, int epilogue, hipStream_t s);
 
 }  // namespace vitk

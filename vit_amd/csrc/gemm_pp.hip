@@ -28,17 +28,28 @@
 // ends the load section publishes them to the phase that reads them, f + 1 or later.  A class
 // overwrites the class 8 places earlier, whose last ds_read was retired (lgkmcnt(0) of both groups)
 // at least two barriers before: W fragments of the first two n-tiles stay in registers for phase 3.
+//
+// The load sections hold no vector ALU work at all: while the partner wave issues MFMAs (at raised
+// priority) every VALU instruction of the loading wave waits for a free issue slot, one per MFMA or
+// so, and the section stretches past the MFMA section it is meant to hide under.  So the LDS stage
+// is a compile-time constant (the K loop walks two K tiles per trip; K/64 must be even), which
+// turns every fragment address into base register + immediate offset, and the per-lane part of the
+// DMA source addresses is computed once per output tile; per K tile only scalar registers change.
+//
+// LDS map: [A stage 0][A stage 1][W stage 0][W stage 1][epilogue windows], 32 KiB each.  An A stage
+// is [group 0: 128 rows][group 1: 128 rows] (group-local rows, so that fragment addresses do not
+// depend on the tile height), a W stage 256 rows; 128 B per row, 16-byte chunk c of row r at slot
+// c ^ ((r >> 1) & 7) (gemm_common.h).
 #include <type_traits>
 
 #include "gemm_plan.h"
 
 namespace vitk {
 
-// PROBE (timing experiments, wrong results): 1 = no DMA after the prologue, 2 = DMA always re-reads the
-// first K tile of the first output tile (cache-hot), 3 = no DMA and no
-// fragment reads, 5 = as 3 and no barriers in the K loop, 6 = no counted DMA waits,
-// 7 = cycle stamps of the phases of 16 K tiles of workgroup 0's last output tile, dumped over the first row of `out`
-template <int EPI, bool GATHER, int PROBE = 0>
+// PROBE (timing experiments): 1 = no DMA after the prologue (wrong results), 7 = the cycles of the six
+// segments of every phase, summed over workgroup 0's K tiles by one wave of each group and written over
+// the first elements of `out` (tools/gemm_stamps.py)
+template <int EPI, int PROBE = 0>
 __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_pp(const GemmArgs p, const PipePlan pl) {
     __shared__ __attribute__((aligned(1024))) char smem[kPipeLdsBytes];
 
@@ -66,82 +77,65 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_pp(const GemmArgs p
     const int my_mt = grp ? pl.mtot - mt0 : mt0;                 // 4..8 (the launcher keeps mtot >= 8)
     const int my_row0 = grp ? rows_g0 : 0;
 
-    // LDS stage image: [A group 0: 128 rows][A group 1: 128 rows][W: 256 rows], 128 B per row, 16-byte
-    // chunk c of row r at slot c ^ ((r >> 1) & 7) (gemm_common.h); group-local A rows so that the
-    // fragment addresses do not depend on the tile height.
+    constexpr int kAStage = 2 * 128 * kRowBytes;                 // 32 KiB: both groups' rows of one stage
+    constexpr int kWRegion = 2 * kAStage;                        // W stages follow the two A stages
 
-    // ---- LDS-DMA issue stream
+    // ---- LDS-DMA issue stream.  Source address = scalar base (tensor + K offset of the K tile) +
+    // per-lane byte offset of the lane's row and 16-byte chunk, the latter fixed per output tile.
     const int srow = lane >> 3;
     const int sswz = (lane >> 4) + 4 * (wave & 1);               // ((image row >> 1) & 7) of this lane's row
     const int schunk = (lane & 7) ^ sswz;                        // source chunk that belongs in this lane's slot
     const char* a_base = reinterpret_cast<const char*>(p.A);
     const char* w_base = reinterpret_cast<const char*>(p.W);
-    const int pmask = (1 << p.p_log2) - 1;
-    const uint32_t plane = (uint32_t)p.img_h * p.img_w;
-    int iss_c = 0, iss_buf = 0, iss_kt = 0, iss_tile = 0, iss_m0, iss_n0;
-    {
+    const uint32_t w_half = (uint32_t)((size_t)128 * p.K * 2);   // 128 weight rows further down
+    int iss_c = 0, iss_buf = 0, iss_kt = 0, iss_tile = 0;
+    uint32_t a_off[2][2], w_off[2];                              // [upper / lower half][group], [first / last n-tiles]
+    auto tile_offsets = [&](int tile_index) {
         int tm, tn;
-        tile_coords(pl, chunk0 + slot, tm, tn);
-        iss_m0 = tm * bme;
-        iss_n0 = tn * BN;
-    }
-    auto a_offset = [&](int gm, uint32_t ka) -> uint32_t {
-        gm = gm < p.M ? gm : p.M - 1;                            // rows past M re-read the last row; never stored
-        if constexpr (GATHER) {
-            const int b = gm / p.npatch, pidx = gm - b * p.npatch;
-            const int ph = pidx / p.grid_w, pw = pidx - ph * p.grid_w;
-            return (uint32_t)((((size_t)b * 3 * p.img_h + ((size_t)ph << p.p_log2)) * p.img_w +
-                               ((size_t)pw << p.p_log2)) * 2) + ka;
-        } else {
-            return (uint32_t)(((size_t)gm * p.lda) * 2) + ka;
-        }
-    };
-    // one class (J = 0..3 as listed above) of the stream: 2 DMA instructions per wave, always
-    auto issue_class = [&](auto jc) {
-        constexpr int J = decltype(jc)::value;
-        char* dst = smem + iss_buf * kStageBytes;
-        if constexpr (J == 0 || J == 3) {
-            constexpr int mh = (J == 3) ? 1 : 0;
-            uint32_t ka;
-            if constexpr (GATHER) {
-                // k = c*P*P + i*P + j  (Conv2d weight [D,3,P,P] flattened; vision_transformer.py:18)
-                const int k = iss_kt * BK + schunk * 8;
-                const int c = k >> (2 * p.p_log2), i = (k >> p.p_log2) & pmask, j = k & pmask;
-                ka = (c * plane + (uint32_t)i * p.img_w + j) * 2;
-            } else {
-                ka = (uint32_t)(iss_kt * BK + schunk * 8) * 2;
-            }
+        tile_coords(pl, tile_index, tm, tn);
+        const int m_first = tm * bme, n_first = tn * BN;
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh) {
             const int piece = mh * 64 + wave * 8;                // first group-local row of this wave's piece
             // pieces past the group's share of the tile (wave-uniform) re-read the tile's first row, so
             // that every wave issues the same number of DMA instructions (the counted waits rely on it)
-            const int r0 = piece < rows_g0 ? piece + srow : 0;
-            const int r1 = piece < rows_g1 ? rows_g0 + piece + srow : 0;
-            __builtin_amdgcn_global_load_lds((gbl_void*)(a_base + a_offset(iss_m0 + r0, ka)),
-                                             (lds_void*)(dst + piece * kRowBytes), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_void*)(a_base + a_offset(iss_m0 + r1, ka)),
-                                             (lds_void*)(dst + (128 + piece) * kRowBytes), 16, 0, 0);
+            int r0 = m_first + (piece < rows_g0 ? piece + srow : 0);
+            int r1 = m_first + (piece < rows_g1 ? rows_g0 + piece + srow : 0);
+            r0 = r0 < p.M ? r0 : p.M - 1;                        // rows past M re-read the last row; never stored
+            r1 = r1 < p.M ? r1 : p.M - 1;
+            a_off[mh][0] = (uint32_t)r0 * (uint32_t)(p.lda * 2) + schunk * 16;
+            a_off[mh][1] = (uint32_t)r1 * (uint32_t)(p.lda * 2) + schunk * 16;
+        }
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+            const int piece = (wave >> 2) * 64 + nh * 32 + (wave & 3) * 8;     // W tile row of the piece
+            w_off[nh] = (uint32_t)(n_first + piece + srow) * (uint32_t)(p.K * 2) + schunk * 16;
+        }
+    };
+    tile_offsets(chunk0 + slot);
+    // one class (J = 0..3 as listed above) of the stream: 2 DMA instructions per wave, always
+    auto issue_class = [&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        const size_t kbytes = (size_t)iss_kt * (BK * 2);
+        if constexpr (J == 0 || J == 3) {
+            constexpr int mh = (J == 3) ? 1 : 0;
+            char* dst = smem + iss_buf * kAStage + (mh * 64 + wave * 8) * kRowBytes;
+            const char* src = a_base + kbytes;
+            __builtin_amdgcn_global_load_lds((gbl_void*)(src + a_off[mh][0]), (lds_void*)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(src + a_off[mh][1]), (lds_void*)(dst + 128 * kRowBytes), 16, 0, 0);
         } else {
             constexpr int nh = (J == 2) ? 1 : 0;
-            const int piece = (wave >> 2) * 64 + nh * 32 + (wave & 3) * 8;     // W tile row of the piece
-            const uint32_t wo = (uint32_t)(((size_t)(iss_n0 + piece + srow) * p.K + iss_kt * BK + schunk * 8) * 2);
-            const uint32_t half = (uint32_t)((size_t)128 * p.K * 2);
-            __builtin_amdgcn_global_load_lds((gbl_void*)(w_base + wo),
-                                             (lds_void*)(dst + kTileBytes + piece * kRowBytes), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_void*)(w_base + wo + half),
-                                             (lds_void*)(dst + kTileBytes + (128 + piece) * kRowBytes), 16, 0, 0);
+            char* dst = smem + kWRegion + iss_buf * kAStage + ((wave >> 2) * 64 + nh * 32 + (wave & 3) * 8) * kRowBytes;
+            const char* src = w_base + kbytes;
+            __builtin_amdgcn_global_load_lds((gbl_void*)(src + w_off[nh]), (lds_void*)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(src + w_half + w_off[nh]), (lds_void*)(dst + 128 * kRowBytes), 16, 0, 0);
         }
         ++iss_c;
         if constexpr (J == 3) {
             iss_buf ^= 1;
-            if constexpr (PROBE == 2) return;
             if (++iss_kt == ktiles) {
                 iss_kt = 0;
-                if (++iss_tile < my_tiles) {
-                    int tm, tn;
-                    tile_coords(pl, chunk0 + slot + iss_tile * slots, tm, tn);
-                    iss_m0 = tm * bme;
-                    iss_n0 = tn * BN;
-                }
+                if (++iss_tile < my_tiles) tile_offsets(chunk0 + slot + iss_tile * slots);
             }
         }
     };
@@ -172,10 +166,10 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_pp(const GemmArgs p
     // the load section's DMA part: next class of the stream, then all but the 4 youngest classes landed
     auto stream = [&](auto jc) {
         if (iss_c < total_classes) {
-            if constexpr (PROBE == 1 || PROBE == 3 || PROBE == 5) { ++iss_c; return; }
+            if constexpr (PROBE == 1) { ++iss_c; return; }
             issue_class(jc);
             stamp(S1{});
-            if constexpr (PROBE != 6) __builtin_amdgcn_s_waitcnt(kWaitVm8);
+            __builtin_amdgcn_s_waitcnt(kWaitVm8);
         } else {
             stamp(S1{});
             __builtin_amdgcn_s_waitcnt(kWaitVm0);                // stream ran dry: everything has landed
@@ -183,43 +177,36 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_pp(const GemmArgs p
         stamp(S2{});
     };
 
-    // ---- MFMA fragments
+    // ---- MFMA fragments: one base register per operand and k-step, everything else immediate offsets
     const int fr = lane & 15, fq = lane >> 4;
     const int foff = fr * kRowBytes + ((fq ^ ((fr >> 1) & 7)) << 4);   // k-step 0; k-step 1 = foff ^ 64
-    const int a_frag = grp * (128 * kRowBytes) + foff;
-    const int w_frag = kTileBytes + wn * 64 * kRowBytes + foff;
+    const char* a_frag[2];
+    const char* w_frag[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        a_frag[kk] = smem + grp * (128 * kRowBytes) + (foff ^ (kk << 6));
+        w_frag[kk] = smem + kWRegion + wn * 64 * kRowBytes + (foff ^ (kk << 6));
+    }
 
     bf16x8 af[4][2], wf0[2][2], wf1[2][2];
     f32x4 acc[4][8];
-    char* stamp_win = smem + 2 * kStageBytes + wave * kEpiBytesPerWave;
-    if constexpr (PROBE == 3 || PROBE == 5) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                af[i][kk] = bf16x8{};
-                wf0[i & 1][kk] = bf16x8{};
-                wf1[i & 1][kk] = bf16x8{};
-                asm volatile("" : "+v"(af[i][kk]), "+v"(wf0[i & 1][kk]), "+v"(wf1[i & 1][kk]));
-            }
-    }
 
-    auto load_w = [&](bf16x8 (&wf)[2][2], const char* st, int nh) {
-        if constexpr (PROBE == 3 || PROBE == 5) return;
+    auto load_w = [&](bf16x8 (&wf)[2][2], auto stc, int nh) {
+        constexpr int stage = decltype(stc)::value;
 #pragma unroll
         for (int n2 = 0; n2 < 2; ++n2)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
-                wf[n2][kk] = *reinterpret_cast<const bf16x8*>(st + ((w_frag + (nh * 2 + n2) * 16 * kRowBytes) ^ (kk << 6)));
+                wf[n2][kk] = *reinterpret_cast<const bf16x8*>(w_frag[kk] + stage * kAStage + (nh * 2 + n2) * 16 * kRowBytes);
     };
-    auto load_a = [&](const char* st, int mh, bool masked) {
-        if constexpr (PROBE == 3 || PROBE == 5) return;
+    auto load_a = [&](auto stc, int mh, bool masked) {
+        constexpr int stage = decltype(stc)::value;
 #pragma unroll
         for (int m4 = 0; m4 < 4; ++m4)
             if (!masked || mh * 4 + m4 < my_mt) {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
-                    af[m4][kk] = *reinterpret_cast<const bf16x8*>(st + ((a_frag + (mh * 4 + m4) * 16 * kRowBytes) ^ (kk << 6)));
+                    af[m4][kk] = *reinterpret_cast<const bf16x8*>(a_frag[kk] + stage * kAStage + (mh * 4 + m4) * 16 * kRowBytes);
             }
     };
     // one quadrant: m-tiles mh*4 .. mh*4+3, n-tiles nh*2, nh*2+1, both k-steps.  Operands swapped
@@ -255,7 +242,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_pp(const GemmArgs p
         __builtin_amdgcn_s_setprio(0);
         if constexpr (PROBE == 7) {
             // segments: [barrier after the previous M, L issue, vmcnt wait, barrier after L, lgkmcnt wait] of this
-            // phase and the MFMA issue of the previous one
+            // phase, then its MFMA issue
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(kWaitLgkm0);
             __builtin_amdgcn_sched_barrier(0);
@@ -273,30 +260,60 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_pp(const GemmArgs p
             seg_sum[ph][5] += (uint32_t)stp[5] - t4;
         }
     };
-    auto kbar = [&]() {
-        if constexpr (PROBE != 5) __builtin_amdgcn_s_barrier();
-    };
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
 
-    // ---- prologue: classes 0..5 of the stream (K tile 0 and half of K tile 1)
+    // the four phases of one K tile held in LDS stage `stc`
+    auto k_tile = [&](auto stc) {
+        // phase 0: upper m-tiles x first n-tiles
+        stamp(S0{});
+        load_w(wf0, stc, 0);
+        load_a(stc, 0, false);
+        stream(J2{});
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        quadrant(wf0, C0{}, C0{}, false);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // phase 1: upper m-tiles x last n-tiles
+        stamp(S0{});
+        load_w(wf1, stc, 1);
+        stream(J3{});
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        quadrant(wf1, C0{}, C1{}, false);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // phase 2: lower m-tiles x last n-tiles
+        stamp(S0{});
+        load_a(stc, 1, true);
+        stream(J0{});
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        quadrant(wf1, C1{}, C1{}, true);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // phase 3: lower m-tiles x first n-tiles (fragments all in registers)
+        stamp(S0{});
+        stream(J1{});
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        quadrant(wf0, C1{}, C0{}, true);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+
+    // ---- prologue: classes 0..5 of the stream (K tile 0 and half of K tile 1; K/64 >= 2)
     issue_class(J0{});
     issue_class(J1{});
-    if (total_classes > 4) {
-        issue_class(J2{});
-        issue_class(J3{});
-        issue_class(J0{});
-        issue_class(J1{});
-        __builtin_amdgcn_s_waitcnt(kWaitVm8);
-    } else {
-        issue_class(J2{});
-        issue_class(J3{});
-        __builtin_amdgcn_s_waitcnt(kWaitVm0);
-    }
+    issue_class(J2{});
+    issue_class(J3{});
+    issue_class(J0{});
+    issue_class(J1{});
+    __builtin_amdgcn_s_waitcnt(kWaitVm8);
     __builtin_amdgcn_s_barrier();
 
     char* win = smem + 2 * kStageBytes + wave * kEpiBytesPerWave;
-    int cur = 0;
     for (int t = 0; t < my_tiles; ++t) {
         int tm, tn;
         tile_coords(pl, chunk0 + slot + t * slots, tm, tn);
@@ -308,45 +325,9 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_pp(const GemmArgs p
 
         if (grp) __builtin_amdgcn_s_barrier();                   // group 1 falls one barrier behind
 
-        for (int kt = 0; kt < ktiles; ++kt) {
-            const char* st = smem + cur * kStageBytes;
-            // phase 0: upper m-tiles x first n-tiles
-            stamp(S0{});
-            load_w(wf0, st, 0);
-            load_a(st, 0, false);
-            stream(J2{});
-            __builtin_amdgcn_sched_barrier(0);
-            kbar();
-            quadrant(wf0, C0{}, C0{}, false);
-            __builtin_amdgcn_sched_barrier(0);
-            kbar();
-            // phase 1: upper m-tiles x last n-tiles
-            stamp(S0{});
-            load_w(wf1, st, 1);
-            stream(J3{});
-            __builtin_amdgcn_sched_barrier(0);
-            kbar();
-            quadrant(wf1, C0{}, C1{}, false);
-            __builtin_amdgcn_sched_barrier(0);
-            kbar();
-            // phase 2: lower m-tiles x last n-tiles
-            stamp(S0{});
-            load_a(st, 1, true);
-            stream(J0{});
-            __builtin_amdgcn_sched_barrier(0);
-            kbar();
-            quadrant(wf1, C1{}, C1{}, true);
-            __builtin_amdgcn_sched_barrier(0);
-            kbar();
-            // phase 3: lower m-tiles x first n-tiles (fragments all in registers)
-            stamp(S0{});
-            stream(J1{});
-            __builtin_amdgcn_sched_barrier(0);
-            kbar();
-            quadrant(wf0, C1{}, C0{}, true);
-            __builtin_amdgcn_sched_barrier(0);
-            kbar();
-            cur ^= 1;
+        for (int kt = 0; kt < ktiles; kt += 2) {                 // K/64 is even: every output tile starts in stage 0
+            k_tile(C0{});
+            k_tile(C1{});
         }
 
         if (!grp) __builtin_amdgcn_s_barrier();                  // group 0 waits for group 1's last quadrant
@@ -374,7 +355,11 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_pp(const GemmArgs p
     }
 }
 
-template <int EPI, bool GATHER>
+// K/64 must be even (the K loop is unrolled over the two LDS stages) and the operand is a plain
+// row-major matrix: the caller routes everything else to the one-group pipelined kernel.
+bool gemm_pp_supports(const GemmArgs& a, bool gather) { return !gather && (a.K / BK) % 2 == 0 && a.K >= 2 * BK; }
+
+template <int EPI>
 static hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
     const int cus = num_cus();
     GemmArgs b = a;
@@ -383,28 +368,23 @@ static hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
     const int tiles = pl.tiles_m * pl.tiles_n;
     const int grid = tiles < cus ? tiles : cus;
     const int probe = (b.order >> 17) & 7;           // debug: bits 17..19 select a timing probe (plain bf16 epilogue only)
-    if constexpr (EPI == EPI_BIAS_BF16 && !GATHER) {
-        if (probe == 1) hipLaunchKernelGGL((gemm_bf16_pp<EPI, GATHER, 1>), dim3(grid), dim3(kGemmThreads), 0, s, b, pl);
-        if (probe == 2) hipLaunchKernelGGL((gemm_bf16_pp<EPI, GATHER, 2>), dim3(grid), dim3(kGemmThreads), 0, s, b, pl);
-        if (probe == 3) hipLaunchKernelGGL((gemm_bf16_pp<EPI, GATHER, 3>), dim3(grid), dim3(kGemmThreads), 0, s, b, pl);
-        if (probe == 5) hipLaunchKernelGGL((gemm_bf16_pp<EPI, GATHER, 5>), dim3(grid), dim3(kGemmThreads), 0, s, b, pl);
-        if (probe == 6) hipLaunchKernelGGL((gemm_bf16_pp<EPI, GATHER, 6>), dim3(grid), dim3(kGemmThreads), 0, s, b, pl);
-        if (probe == 7) hipLaunchKernelGGL((gemm_bf16_pp<EPI, GATHER, 7>), dim3(grid), dim3(kGemmThreads), 0, s, b, pl);
-        if (probe) return hipGetLastError();
+    if constexpr (EPI == EPI_BIAS_BF16) {
+        if (probe == 1) hipLaunchKernelGGL((gemm_bf16_pp<EPI, 1>), dim3(grid), dim3(kGemmThreads), 0, s, b, pl);
+        if (probe == 7) hipLaunchKernelGGL((gemm_bf16_pp<EPI, 7>), dim3(grid), dim3(kGemmThreads), 0, s, b, pl);
+        if (probe == 1 || probe == 7) return hipGetLastError();
     }
-    hipLaunchKernelGGL((gemm_bf16_pp<EPI, GATHER>), dim3(grid), dim3(kGemmThreads), 0, s, b, pl);
+    hipLaunchKernelGGL((gemm_bf16_pp<EPI>), dim3(grid), dim3(kGemmThreads), 0, s, b, pl);
     return hipGetLastError();
 }
 
-hipError_t launch_gemm_pp(const GemmArgs& a, int epilogue, bool gather, hipStream_t s) {
-    if (gather) return launch_pp<EPI_PATCH_F32, true>(a, s);
+hipError_t launch_gemm_pp(const GemmArgs& a, int epilogue, hipStream_t s) {
     switch (epilogue) {
-        case EPI_BIAS_BF16: return launch_pp<EPI_BIAS_BF16, false>(a, s);
-        case EPI_BIAS_GELU_BF16: return launch_pp<EPI_BIAS_GELU_BF16, false>(a, s);
-        case EPI_BIAS_RESID_F32: return launch_pp<EPI_BIAS_RESID_F32, false>(a, s);
-        case EPI_QKV_BF16: return launch_pp<EPI_QKV_BF16, false>(a, s);
-        case EPI_BIAS_F32: return launch_pp<EPI_BIAS_F32, false>(a, s);
-        case EPI_BIAS_TANH_BF16: return launch_pp<EPI_BIAS_TANH_BF16, false>(a, s);
+        case EPI_BIAS_BF16: return launch_pp<EPI_BIAS_BF16>(a, s);
+        case EPI_BIAS_GELU_BF16: return launch_pp<EPI_BIAS_GELU_BF16>(a, s);
+        case EPI_BIAS_RESID_F32: return launch_pp<EPI_BIAS_RESID_F32>(a, s);
+        case EPI_QKV_BF16: return launch_pp<EPI_QKV_BF16>(a, s);
+        case EPI_BIAS_F32: return launch_pp<EPI_BIAS_F32>(a, s);
+        case EPI_BIAS_TANH_BF16: return launch_pp<EPI_BIAS_TANH_BF16>(a, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -33,8 +33,9 @@ __device__ __forceinline__ void advance_row(int& b, int& t, int step, int per) {
 // wave-private LDS window `win` and are read back as 16-byte row pieces, so every global store
 // (and residual / pos-embed load) instruction covers whole 128-byte lines instead of 32-byte
 // fragments of 16 different rows.  Rows at or past `row_limit` (relative to mw) are not stored;
-// MASKED = false promises my_mt == 8 and row_limit >= 128 and drops every per-row branch.
-template <int EPI, bool MASKED>
+// MASKED = false promises my_mt == 8 and row_limit >= 128 and drops every per-row branch.  AHEAD (1 or 2)
+// is the number of addend batches requested ahead of their use (residual / pos-embed epilogues).
+template <int EPI, bool MASKED, int AHEAD = 1>
 __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&acc)[4][8], char* win, int mw,
                                               int nw, int my_mt, int row_limit, int lane) {
     const int fr = lane & 15, fq = lane >> 4;
@@ -116,9 +117,10 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
         }
     } else {
         // window = 16 rows x 256 B; 16-byte chunk c of row r lives at 256 r + 16 (c ^ (r & 15)).
-        // The residual / pos-embed addend of a quarter sub-tile (2 m-tiles = 8 loads per lane) is
-        // requested up front, before any store of that quarter: out may alias resid, so loads placed
-        // after stores would be kept behind them, one memory round trip per 16 bytes.
+        // The residual / pos-embed addend is requested AHEAD batches (of 2 m-tiles = 8 loads per lane)
+        // ahead of its use, so that one memory round trip covers a quarter of the sub-tile instead of
+        // each 16 bytes; a batch's loads are issued before the stores of the batch that follows its
+        // predecessor (out may alias resid, but never within rows still to be loaded).
         const int rc = lane >> 4, cc = lane & 15;    // read-back role: row within 4, 16-byte chunk
         const int ncol = nw + cc * 4;
         f32x4 bias_rb = {0.f, 0.f, 0.f, 0.f};       // bias in read-back layout: added after the transpose
@@ -130,11 +132,10 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
         const char* resid_b = reinterpret_cast<const char*>(p.resid);
         const char* pos_b = reinterpret_cast<const char*>(p.pos);
         char* out_b = reinterpret_cast<char*>(p.out);
-#pragma unroll
-        for (int batch = 0; batch < 8 / QB; ++batch) {
-            if (MASKED && batch * QB >= my_mt) break;
-            f32x4 add[QB][4];
-            uint32_t orow[QB][4];     // output row of each piece (PATCH only; else it is mw + local row)
+        constexpr int NB = 8 / QB;                   // addend batches
+        f32x4 add[AHEAD][QB][4];                     // AHEAD batches of addend loads in flight
+        uint32_t orow[AHEAD][QB][4];                     // output row of each piece (PATCH only; else it is mw + local row)
+        auto load_batch = [&](int batch, f32x4 (&ad)[QB][4], uint32_t (&orw)[QB][4]) {
 #pragma unroll
             for (int q = 0; q < QB; ++q) {
                 const int mt = batch * QB + q;
@@ -152,14 +153,26 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
                     if constexpr (EPI == EPI_PATCH_F32) {
                         // patch row (b, pidx) lands at token 1 + pidx (the cls token is row 0) and takes
                         // that token's position embedding: vision_transformer.py:47-50
-                        orow[q][i] = (uint32_t)(rb * p.ntok + 1 + rt);
-                        add[q][i] = *reinterpret_cast<const f32x4*>(pos_b + ((uint32_t)(1 + rt) * p.N + ncol) * 4u);
+                        orw[q][i] = (uint32_t)(rb * p.ntok + 1 + rt);
+                        ad[q][i] = *reinterpret_cast<const f32x4*>(pos_b + ((uint32_t)(1 + rt) * p.N + ncol) * 4u);
                         advance_row(rb, rt, 4, p.npatch);
                     } else if constexpr (EPI == EPI_BIAS_RESID_F32) {
-                        add[q][i] = *reinterpret_cast<const f32x4*>(resid_b + ((uint32_t)m * p.ldo + ncol) * 4u);
+                        ad[q][i] = *reinterpret_cast<const f32x4*>(resid_b + ((uint32_t)m * p.ldo + ncol) * 4u);
                     }
                 }
             }
+        };
+        if constexpr (ADDEND) {
+            load_batch(0, add[0], orow[0]);
+            if constexpr (AHEAD == 2) {
+                if (!MASKED || QB < my_mt) load_batch(1, add[1], orow[1]);
+            }
+        }
+#pragma unroll
+        for (int batch = 0; batch < NB; ++batch) {
+            if (MASKED && batch * QB >= my_mt) break;
+            f32x4 (&ad)[QB][4] = add[batch % AHEAD];
+            uint32_t (&orw)[QB][4] = orow[batch % AHEAD];
 #pragma unroll
             for (int q = 0; q < QB; ++q) {
                 const int mt = batch * QB + q;
@@ -173,12 +186,16 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
                     const int r = i * 4 + rc;
                     f32x4 v = *reinterpret_cast<const f32x4*>(win + r * 256 + ((cc ^ r) << 4));
                     v = v + bias_rb;
-                    if constexpr (ADDEND) v = v + add[q][i];
+                    if constexpr (ADDEND) v = v + ad[q][i];
                     const int lr = mt * 16 + r;
-                    const uint32_t orow_i = (EPI == EPI_PATCH_F32) ? orow[q][i] : (uint32_t)(mw + lr);
+                    const uint32_t orow_i = (EPI == EPI_PATCH_F32) ? orw[q][i] : (uint32_t)(mw + lr);
                     if (!MASKED || lr < row_limit)
                         *reinterpret_cast<f32x4*>(out_b + (orow_i * p.ldo + ncol) * 4u) = v;
                 }
+            }
+            // a later batch goes into the registers this one has just released
+            if constexpr (ADDEND) {
+                if (batch + AHEAD < NB && (!MASKED || (batch + AHEAD) * QB < my_mt)) load_batch(batch + AHEAD, ad, orw);
             }
         }
     }

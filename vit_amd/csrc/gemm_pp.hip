@@ -46,7 +46,8 @@
 
 namespace vitk {
 
-// PROBE (timing experiments): 1 = no DMA after the prologue (wrong results), 7 = the cycles of the six
+// PROBE (timing experiments): 1 = no DMA after the prologue (wrong results), 2 = no epilogue (no results),
+// 7 = the cycles of the six
 // segments of every phase, summed over workgroup 0's K tiles by one wave of each group and written over
 // the first elements of `out` (tools/gemm_stamps.py)
 template <int EPI, int PROBE = 0>
@@ -351,7 +352,14 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_pp(const GemmArgs p
         // here, per tile, instead of being hoisted above the K loop and held (or spilled) across it.
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
-        epilogue_tile<EPI, true>(p, acc, win, mw, nw, my_mt, row_limit, lane_e);
+        if constexpr (PROBE == 2) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) asm volatile("" ::"v"(acc[nt][mt]));
+        } else {
+            epilogue_tile<EPI, true, 2>(p, acc, win, mw, nw, my_mt, row_limit, lane_e);
+        }
     }
 }
 
@@ -371,7 +379,8 @@ static hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
     if constexpr (EPI == EPI_BIAS_BF16) {
         if (probe == 1) hipLaunchKernelGGL((gemm_bf16_pp<EPI, 1>), dim3(grid), dim3(kGemmThreads), 0, s, b, pl);
         if (probe == 7) hipLaunchKernelGGL((gemm_bf16_pp<EPI, 7>), dim3(grid), dim3(kGemmThreads), 0, s, b, pl);
-        if (probe == 1 || probe == 7) return hipGetLastError();
+        if (probe == 2) hipLaunchKernelGGL((gemm_bf16_pp<EPI, 2>), dim3(grid), dim3(kGemmThreads), 0, s, b, pl);
+        if (probe == 1 || probe == 2 || probe == 7) return hipGetLastError();
     }
     hipLaunchKernelGGL((gemm_bf16_pp<EPI>), dim3(grid), dim3(kGemmThreads), 0, s, b, pl);
     return hipGetLastError();

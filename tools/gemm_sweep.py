@@ -2,7 +2,7 @@
 rounds, inside one process (median and min over the rounds are printed), because launch-to-launch
 clock and box-to-box differences are larger than most kernel changes.
 
-    python tools/gemm_sweep.py [--variant=0,4,...] [--epi=bias|resid|gelu] [--rounds=5] M N K [M N K ...]
+    python tools/gemm_sweep.py [--variant=0,4,...] [--epi=bias|resid|gelu] [--rounds=5] [--launches=10] M N K [M N K ...]
 """
 import os
 import statistics
@@ -16,7 +16,7 @@ from vit_amd import lib, ops   # noqa: E402
 
 def main():
     argv = sys.argv[1:]
-    variants, epi, rounds = [0], "bias", 5
+    variants, epi, rounds, launches = [0], "bias", 5, 10
     while argv and argv[0].startswith("--"):
         k, v = argv.pop(0)[2:].split("=")
         if k == "variant":
@@ -25,9 +25,11 @@ def main():
             epi = v
         elif k == "rounds":
             rounds = int(v)
+        elif k == "launches":
+            launches = int(v)
     a = [int(v) for v in argv]
     dev = "cuda:0"
-    print(f"# epilogue {epi}, {rounds} interleaved rounds of 10 launches: median us (min us) median TFLOP/s")
+    print(f"# epilogue {epi}, {rounds} interleaved rounds of {launches} launches: median us (min us) median TFLOP/s")
     for M, N, K in zip(a[0::3], a[1::3], a[2::3]):
         A = torch.randn(M, K, device=dev).to(torch.bfloat16)
         W = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
@@ -49,12 +51,12 @@ def main():
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                for _ in range(10):
+                for _ in range(launches):
                     run()
                 e1.record()
                 torch.cuda.synchronize()
                 if r:
-                    times[v].append(e0.elapsed_time(e1) / 10 * 1e3)
+                    times[v].append(e0.elapsed_time(e1) / launches * 1e3)
         print(f"M={M} N={N} K={K}")
         for v in variants:
             med, lo = statistics.median(times[v]), min(times[v])

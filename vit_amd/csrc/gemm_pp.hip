@@ -212,8 +212,10 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_pp(const GemmArgs p
     };
     // one quadrant: m-tiles mh*4 .. mh*4+3, n-tiles nh*2, nh*2+1, both k-steps.  Operands swapped
     // (MFMA row index = n, column index = m), so a lane ends up with 4 consecutive n of one row m.
-    auto quadrant = [&](const bf16x8 (&wf)[2][2], auto mhc, auto nhc, bool masked) {
+    auto quadrant = [&](const bf16x8 (&wf)[2][2], auto mhc, auto nhc, bool masked, auto firstc) {
         constexpr int mh = decltype(mhc)::value, nh = decltype(nhc)::value;
+        constexpr bool first = decltype(firstc)::value;      // first K tile of an output tile: accumulate onto 0
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         stamp(S3{});
         __builtin_amdgcn_s_waitcnt(kWaitLgkm0);
         stamp(S4{});
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_pp(const GemmArgs p
 #pragma unroll
                     for (int n2 = 0; n2 < 2; ++n2)
                         acc[nh * 2 + n2][mh * 4 + m4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            wf[n2][kk], af[m4][kk], acc[nh * 2 + n2][mh * 4 + m4], 0, 0, 0);
+                            wf[n2][kk], af[m4][kk], (first && kk == 0) ? zero : acc[nh * 2 + n2][mh * 4 + m4], 0, 0, 0);
         } else {
             // m-tiles past the wave's share are skipped (wave-uniform, monotonic: an early-exit chain)
 #pragma unroll
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_pp(const GemmArgs p
 #pragma unroll
                         for (int n2 = 0; n2 < 2; ++n2)
                             acc[nh * 2 + n2][mh * 4 + m4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                wf[n2][kk], af[m4][kk], acc[nh * 2 + n2][mh * 4 + m4], 0, 0, 0);
+                                wf[n2][kk], af[m4][kk], (first && kk == 0) ? zero : acc[nh * 2 + n2][mh * 4 + m4], 0, 0, 0);
                 }
         }
         __builtin_amdgcn_s_setprio(0);
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_pp(const GemmArgs p
     using C1 = std::integral_constant<int, 1>;
 
     // the four phases of one K tile held in LDS stage `stc`
-    auto k_tile = [&](auto stc) {
+    auto k_tile = [&](auto stc, auto firstc) {
         // phase 0: upper m-tiles x first n-tiles
         stamp(S0{});
         load_w(wf0, stc, 0);
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_pp(const GemmArgs p
         stream(J2{});
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
-        quadrant(wf0, C0{}, C0{}, false);
+        quadrant(wf0, C0{}, C0{}, false, firstc);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         // phase 1: upper m-tiles x last n-tiles
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_pp(const GemmArgs p
         stream(J3{});
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
-        quadrant(wf1, C0{}, C1{}, false);
+        quadrant(wf1, C0{}, C1{}, false, firstc);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         // phase 2: lower m-tiles x last n-tiles
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_pp(const GemmArgs p
         stream(J0{});
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
-        quadrant(wf1, C1{}, C1{}, true);
+        quadrant(wf1, C1{}, C1{}, true, firstc);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         // phase 3: lower m-tiles x first n-tiles (fragments all in registers)
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_pp(const GemmArgs p
         stream(J1{});
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
-        quadrant(wf0, C1{}, C0{}, true);
+        quadrant(wf0, C1{}, C0{}, true, firstc);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
     };
@@ -319,16 +321,26 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_pp(const GemmArgs p
         int tm, tn;
         tile_coords(pl, chunk0 + slot + t * slots, tm, tn);
         const int m0 = tm * bme, n0 = tn * BN;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < 8; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
         if (grp) __builtin_amdgcn_s_barrier();                   // group 1 falls one barrier behind
 
-        for (int kt = 0; kt < ktiles; kt += 2) {                 // K/64 is even: every output tile starts in stage 0
-            k_tile(C0{});
-            k_tile(C1{});
+        // K/64 is even, so every output tile starts in stage 0.  The first K tile's first k-step takes 0 as
+        // its C operand: no accumulator clearing, and m-tiles past the wave's share stay untouched.
+        if constexpr (PROBE == 3) {                              // timing probe: clear the accumulators instead
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int kt = 0; kt < ktiles; kt += 2) {
+                k_tile(C0{}, std::false_type{});
+                k_tile(C1{}, std::false_type{});
+            }
+        } else {
+            k_tile(C0{}, std::true_type{});
+            k_tile(C1{}, std::false_type{});
+            for (int kt = 2; kt < ktiles; kt += 2) {
+                k_tile(C0{}, std::false_type{});
+                k_tile(C1{}, std::false_type{});
+            }
         }
 
         if (!grp) __builtin_amdgcn_s_barrier();                  // group 0 waits for group 1's last quadrant
@@ -380,7 +392,8 @@ static hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
         if (probe == 1) hipLaunchKernelGGL((gemm_bf16_pp<EPI, 1>), dim3(grid), dim3(kGemmThreads), 0, s, b, pl);
         if (probe == 7) hipLaunchKernelGGL((gemm_bf16_pp<EPI, 7>), dim3(grid), dim3(kGemmThreads), 0, s, b, pl);
         if (probe == 2) hipLaunchKernelGGL((gemm_bf16_pp<EPI, 2>), dim3(grid), dim3(kGemmThreads), 0, s, b, pl);
-        if (probe == 1 || probe == 2 || probe == 7) return hipGetLastError();
+        if (probe == 3) hipLaunchKernelGGL((gemm_bf16_pp<EPI, 3>), dim3(grid), dim3(kGemmThreads), 0, s, b, pl);
+        if (probe == 1 || probe == 2 || probe == 3 || probe == 7) return hipGetLastError();
     }
     hipLaunchKernelGGL((gemm_bf16_pp<EPI>), dim3(grid), dim3(kGemmThreads), 0, s, b, pl);
     return hipGetLastError();

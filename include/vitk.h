@@ -41,11 +41,19 @@ int vitk_version(void);
 /* Message for the last non-zero return on the calling thread ("" if none). */
 const char* vitk_last_error(void);
 
-/* Test hook: choose an alternative implementation of the tiled GEMM
- * (low 4 bits: 0 = pipelined kernel, 1 = basic kernel with LDS-DMA staging, 2 = force the small
- * untiled kernel, 3 = basic kernel with register staging; bits 4 and up: workgroup -> tile order)
- * and of attention (0 = transposed LDS reads of V, 1 = V stored transposed in LDS).
- * Process-global; results are identical across variants up to fp32 summation order. */
+/* Test and measurement hook: choose an alternative implementation of the tiled GEMM and of attention.
+ * gemm_variant, low 4 bits: 0 (and 4) = default (two-group phased kernel where K/64 is even and A is a
+ *   plain matrix, else the one-group pipelined kernel), 1 = basic kernel with LDS-DMA staging, 2 = force
+ *   the small untiled kernel, 3 = basic kernel with register staging, 5 = one-group pipelined kernel.
+ *   gemm_variant >> 4 (= "order"): bits 0-3 tile order (1 = no n-grouping, 3 = group width from bits
+ *   4-7), bits 8-12 force the tile height (in 16-row units).
+ *   Timing probes, which produce WRONG OR NO RESULTS: order bits 17-19 on the bias -> bf16 epilogue of
+ *   the default kernel (1 = no DMA, 2 = no epilogue, 3 = accumulator clearing instead of the zero C
+ *   operand, 7 = cycle stamps written over out[0..]), order bit 22 = bf16 epilogues without stores.
+ * attention_variant: bit 0 = V stored transposed in LDS instead of transposed LDS reads; bits 2-3 =
+ *   timing probes (wrong results).
+ * Process-global; apart from the probes, results are identical across variants up to fp32 summation
+ * order. */
 void vitk_set_debug_variant(int gemm_variant, int attention_variant);
 
 /* y[r, :] = LayerNorm(x[r, :]) * gamma + beta over D columns, fp32 statistics.

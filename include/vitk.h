@@ -102,7 +102,8 @@ int vitk_qkv_proj(const void* A, const void* W, const float* bias, void* qkv, in
                   int hd, void* stream);
 
 /* ctx[b, t, h*hd + e] = sum_s softmax_s(q[b,h,t,:] . k[b,h,s,:] * scale) * v[b,h,s,e]
- * q, k, v: bf16 [batch, heads, ntok, hd]; ctx: bf16 [batch, ntok, heads*hd].  hd == 64, ntok <= 608.
+ * q, k, v: bf16 [batch, heads, ntok, hd]; ctx: bf16 [batch, ntok, heads*hd].  hd == 64 with ntok <= 608, or hd == 96 with
+ * ntok <= 288 (K and V of one head stay resident in LDS); other head sizes return VITK_ERR_UNSUPPORTED.
  * Replaces q@k^T, scaling, softmax, @v, transpose, reshape at models/transformer.py:43-46. */
 int vitk_attention(const void* q, const void* k, const void* v, void* ctx, int batch, int heads, int ntok,
                    int hd, float scale, void* stream);

@@ -161,8 +161,16 @@ def _attn_ref(q, k, v, scale):
 @pytest.mark.parametrize("B,H,N", [(2, 12, 197), (1, 12, 577), (3, 2, 1), (2, 3, 32), (2, 3, 33), (1, 4, 224),
                                    (1, 2, 225), (2, 16, 197), (1, 1, 608)])
 def test_attention(B, H, N, variant):
+    _attention_case(B, H, N, 64, variant)
+
+
+@pytest.mark.parametrize("B,H,N", [(2, 8, 197), (3, 2, 1), (2, 3, 32), (2, 3, 33), (1, 4, 224), (1, 2, 225), (1, 1, 288)])
+def test_attention_head_dim_96(B, H, N):
+    _attention_case(B, H, N, 96, 0)
+
+
+def _attention_case(B, H, N, hd, variant):
     lib.load().vitk_set_debug_variant(0, variant)
-    hd = 64
     qkv = to16(rnd(3, B, H, N, hd, seed=N + variant))
     want = _attn_ref(qkv[0].float(), qkv[1].float(), qkv[2].float(), hd ** -0.5)
     ctx = torch.full((B, N, H * hd), float("nan"), dtype=torch.bfloat16, device=DEV)
@@ -175,14 +183,22 @@ def test_attention(B, H, N, variant):
 def test_attention_online_softmax_rescale_is_exercised(variant):
     """A key far down the sequence dominates: the running max jumps in a late key block, so every
     earlier partial sum must be rescaled.  Scores of ~+-60 also check the exp2 argument handling."""
+    _rescale_case(64, variant)
+
+
+def test_attention_online_softmax_rescale_head_dim_96():
+    _rescale_case(96, 0)
+
+
+def _rescale_case(hd, variant):
     lib.load().vitk_set_debug_variant(0, variant)
-    B, H, N, hd = 1, 2, 197, 64
+    B, H, N = 1, 2, 197
     qkv = to16(rnd(3, B, H, N, hd, seed=7))
     qkv[1, 0, 0, 150] = qkv[0, 0, 0, 10] * 6.0          # key 150 aligned with query 10 of head 0
     qkv[1, 0, 1, 190] = qkv[0, 0, 1, 100] * 8.0
-    want = _attn_ref(qkv[0].float(), qkv[1].float(), qkv[2].float(), 0.125)
+    want = _attn_ref(qkv[0].float(), qkv[1].float(), qkv[2].float(), hd ** -0.5)
     ctx = torch.empty(B, N, H * hd, dtype=torch.bfloat16, device=DEV)
-    ops.attention(qkv.to(DEV), ctx, 0.125)
+    ops.attention(qkv.to(DEV), ctx, hd ** -0.5)
     assert torch.isfinite(f32(ctx)).all()
     assert torch.allclose(f32(ctx), want, rtol=2e-2, atol=6e-3)
 
@@ -200,7 +216,7 @@ def test_attention_custom_scale_and_row_independence():
 
 
 def test_unsupported_head_dim_raises():
-    qkv = torch.zeros(3, 1, 8, 197, 96, dtype=torch.bfloat16, device=DEV)
-    ctx = torch.empty(1, 197, 768, dtype=torch.bfloat16, device=DEV)
-    with pytest.raises(lib.VitkError, match="hd=96"):
+    qkv = torch.zeros(3, 1, 8, 197, 80, dtype=torch.bfloat16, device=DEV)
+    ctx = torch.empty(1, 197, 640, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(lib.VitkError, match="hd=80"):
         ops.attention(qkv, ctx, 0.1)

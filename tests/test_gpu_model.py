@@ -18,7 +18,7 @@ DEV = "cuda:0"
 TOL_BF16 = 1e-2
 
 
-@pytest.mark.parametrize("name", ["b16_224_ref", "b16_224_pert", "b16_384_ref", "l16_224_ref"])
+@pytest.mark.parametrize("name", ["b16_224_ref", "b16_224_pert", "b16_384_ref", "l16_224_ref", "s16_224_ref"])
 def test_logits_match_reference(name):
     meta, g = load_golden(name)
     cfg, sd, x = golden_inputs(meta)
@@ -91,12 +91,15 @@ def test_weight_update_invalidates_cache_and_extra_shapes():
         m(xd)                                                   # grad enabled: forward-only path
 
 
-def test_s16_head_dim_96_is_rejected_not_faked():
-    """ViT-S/16 has head_dim 96, which the attention kernel does not cover yet: the module must
-    raise rather than fall back to any other implementation."""
-    meta, _ = load_golden("s16_224_ref")
-    cfg, sd, x = golden_inputs(meta)
-    m = build_model("s16", 224, sd, DEV)
-    with pytest.raises(vit_amd.VitkError, match="hd=96"):
-        with torch.no_grad():
-            m(x[:1].to(DEV))
+def test_unsupported_head_dim_is_rejected_not_faked():
+    """head_dim 80 (ViT-H/14) is not covered by the attention kernel: the call must raise rather than
+    fall back to any other implementation."""
+    from vit_amd import ops
+    qkv = torch.zeros(3, 1, 2, 197, 80, dtype=torch.bfloat16, device=DEV)
+    ctx = torch.empty(1, 197, 160, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(vit_amd.VitkError, match="hd=80"):
+        ops.attention(qkv, ctx, 80 ** -0.5)
+    qkv = torch.zeros(3, 1, 2, 577, 96, dtype=torch.bfloat16, device=DEV)
+    ctx = torch.empty(1, 577, 192, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(vit_amd.VitkError, match="LDS-resident"):
+        ops.attention(qkv, ctx, 96 ** -0.5)                    # K and V of a 577-token head do not fit at hd=96

@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--img-size", type=int, default=224)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
+                    help="compute mode; the headline metric is bf16, fp32 is the reference-accuracy mode")
     a = ap.parse_args()
 
     rank, world, local = vdist.init_from_env()
@@ -101,6 +103,7 @@ def main():
     model = model.to_empty(device=dev)
     model.load_state_dict(sd, strict=True)
     model.eval()
+    model.set_precision(a.precision)
     # rank r owns images [r*B, (r+1)*B) of the synthetic stream; generate a few and tile them
     lo = rank * a.batch
     uniq = min(a.batch, 32)
@@ -108,7 +111,7 @@ def main():
     x = x.repeat((a.batch + uniq - 1) // uniq, 1, 1, 1)[: a.batch].to(dev).to(torch.bfloat16).contiguous()
 
     ntok = (a.img_size // cfg["patches"]) ** 2 + 1
-    timer = KernelTimer("gemm_bias_gelu")
+    timer = KernelTimer("gemm_bias_gelu" if a.precision == "bf16" else "attention_f32")
     ops.set_event_hook(timer)
 
     with torch.no_grad():
@@ -138,10 +141,10 @@ def main():
         k_ms = timer.mean_ms()
         achieved = k_flops / (k_ms * 1e-3) / 1e12
         out = {
-            "metric": f"images/sec (whole node) ViT-{a.arch.upper()[0]}/{cfg['patches']} {a.img_size}px bf16 fwd",
+            "metric": f"images/sec (whole node) ViT-{a.arch.upper()[0]}/{cfg['patches']} {a.img_size}px {a.precision} fwd",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if a.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"ViT-{a.arch.upper()[0]}/{cfg['patches']} {a.img_size}px forward, "
                                    f"batch {a.batch} per GPU, random-init weights"
                                    + (" (BASELINE configs[1])" if (a.arch, a.img_size, a.batch) == ("b16", 224, 256) else ""),
@@ -154,6 +157,8 @@ def main():
                          "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_BF16_PEAK, 4),
                          "avg_launch_ms": round(k_ms, 4), "launches": len(timer.pairs), "traffic": None},
         }
+        if a.precision != "bf16":
+            out.pop("roofline")          # the roofline entry describes the bf16 fc1 kernel only
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.arch, a.img_size, sd, 32 if a.img_size <= 224 else 8)
         print(json.dumps(out), flush=True)

@@ -108,6 +108,38 @@ int vitk_qkv_proj(const void* A, const void* W, const float* bias, void* qkv, in
 int vitk_attention(const void* q, const void* k, const void* v, void* ctx, int batch, int heads, int ntok,
                    int hd, float scale, void* stream);
 
+/* ---- fp32 compute mode -------------------------------------------------------------------------
+ * The reference runs in the dtype of its parameters (fp32 unless the caller casts the model); these
+ * entry points restate the same ops with f32 operands, f32 storage and exact f32 multiply-add (the
+ * f32-input MFMA), for callers that need max-abs logit error <= 1e-4 against the reference's CPU
+ * forward instead of bf16 throughput.  LayerNorm is vitk_layernorm with out_dtype = VITK_F32. */
+
+#define VITK_EPI_BIAS 0      /* out = A W^T + bias */
+#define VITK_EPI_GELU 1      /* out = gelu(A W^T + bias), exact erf (nn.GELU(), models/transformer.py:16) */
+#define VITK_EPI_RESIDUAL 2  /* out = resid + A W^T + bias; out may alias resid (models/transformer.py:69,75) */
+#define VITK_EPI_TANH 3      /* out = tanh(A W^T + bias) (models/vision_transformer.py:53-54) */
+
+/* A f32 [M,K], W f32 [N,K] (nn.Linear weight), bias f32 [N] or NULL, out f32 [M,N]; any M, N, K.
+ * Replaces nn.Linear (+ GELU / residual add / tanh) at models/transformer.py:21-25,42,47,69,75 and
+ * models/vision_transformer.py:53-55 when the model computes in fp32. */
+int vitk_gemm_f32(const float* A, const float* W, const float* bias, const float* resid, float* out, int M, int N,
+                  int K, int epilogue, void* stream);
+
+/* qkv f32 [3, batch, heads, ntok, hd] <- (A W^T + bias) split head-major; A f32 [batch*ntok, heads*hd].
+ * fp32 counterpart of vitk_qkv_proj (models/transformer.py:42). */
+int vitk_qkv_proj_f32(const float* A, const float* W, const float* bias, float* qkv, int batch, int ntok, int heads,
+                      int hd, void* stream);
+
+/* fp32 counterpart of vitk_patch_embed: img f32 [batch,3,img_h,img_w], w f32 [D, 3*patch*patch]; any patch
+ * size (14 for ViT-H/14 included).  models/vision_transformer.py:47-50. */
+int vitk_patch_embed_f32(const float* img, const float* w, const float* bias, const float* cls, const float* pos,
+                         float* x, int batch, int img_h, int img_w, int patch, int D, void* stream);
+
+/* fp32 counterpart of vitk_attention: q, k, v f32 [batch, heads, ntok, hd], ctx f32 [batch, ntok, heads*hd];
+ * hd in {16, 32, 64, 80, 96, 128}, ntok <= 1024.  models/transformer.py:43-46. */
+int vitk_attention_f32(const float* q, const float* k, const float* v, float* ctx, int batch, int heads, int ntok,
+                       int hd, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,8 +35,8 @@ def test_argument_errors_are_reported_not_launched():
     p = ctypes.addressof(buf)
     p = (p + 15) & ~15
     assert L.vitk_layernorm(p, 700, p, p, p, 700, 4, 700, 1e-6, 1, None) == 2      # D not supported
-    assert L.vitk_attention(p, p, p, p, 1, 1, 197, 96, 0.1, None) == 2             # head_dim 96
-    assert b"hd=96" in L.vitk_last_error()
+    assert L.vitk_attention(p, p, p, p, 1, 1, 197, 80, 0.1, None) == 2             # head_dim 80
+    assert b"hd=80" in L.vitk_last_error()
     assert L.vitk_attention(p, p, p, p, 1, 1, 700, 64, 0.1, None) == 2             # too many tokens
     assert L.vitk_gemm_bias_gelu(p, p, p, p, 16, 16, 40, None) == 2                # K % 32
     assert L.vitk_gemm_bias(p, p, p, p, 16, 16, 64, 7, None) == 2                  # dtype code
@@ -44,6 +44,10 @@ def test_argument_errors_are_reported_not_launched():
     assert L.vitk_patch_embed(p, p, p, p, p, p, 1, 224, 224, 14, 1280, None) == 2  # patch 14
     assert L.vitk_qkv_proj(p, p, p, p, 1, 197, 12, 60, None) == 2
     assert L.vitk_cast_f32_bf16(p, p, 12, None) == 1
+    assert L.vitk_gemm_f32(p, p, p, None, p, 16, 16, 64, 2, None) == 1             # residual epilogue without residual
+    assert L.vitk_gemm_f32(p, p, p, None, p, 16, 16, 64, 9, None) == 1             # epilogue code
+    assert L.vitk_attention_f32(p, p, p, p, 1, 1, 197, 48, 0.1, None) == 2         # head_dim
+    assert L.vitk_attention_f32(p, p, p, p, 1, 1, 2000, 64, 0.1, None) == 2        # too many tokens
     assert L.vitk_gemm_bias(p + 4, p, p, p, 16, 16, 64, 1, None) == 1              # misaligned
 
 

@@ -61,7 +61,7 @@ int dense(const char* name, const void* A, const void* W, const float* bias, con
 
 extern "C" {
 
-int vitk_version(void) { return 1; }
+int vitk_version(void) { return 2; }
 
 const char* vitk_last_error(void) { return g_err; }
 
@@ -178,6 +178,54 @@ int vitk_attention(const void* q, const void* k, const void* v, void* ctx, int b
     return launched(launch_attention(q, k, v, ctx, batch, heads, ntok, hd, scale, g_attn_variant,
                                      reinterpret_cast<hipStream_t>(stream)),
                     "vitk_attention");
+}
+
+// ---- fp32 compute mode ------------------------------------------------------------------------
+
+int vitk_gemm_f32(const float* A, const float* W, const float* bias, const float* resid, float* out, int M, int N,
+                  int K, int epilogue, void* stream) {
+    if (!A || !W || !out) return fail(VITK_ERR_INVALID, "vitk_gemm_f32: null pointer");
+    if (M <= 0 || N <= 0 || K <= 0) return fail(VITK_ERR_INVALID, "vitk_gemm_f32: non-positive size %dx%dx%d", M, N, K);
+    if (epilogue < VITK_EPI_BIAS || epilogue > VITK_EPI_TANH)
+        return fail(VITK_ERR_INVALID, "vitk_gemm_f32: epilogue=%d", epilogue);
+    if (epilogue == VITK_EPI_RESIDUAL && !resid) return fail(VITK_ERR_INVALID, "vitk_gemm_f32: null residual");
+    return launched(launch_gemm_f32(A, W, bias, resid, out, M, N, K, epilogue, reinterpret_cast<hipStream_t>(stream)),
+                    "vitk_gemm_f32");
+}
+
+int vitk_qkv_proj_f32(const float* A, const float* W, const float* bias, float* qkv, int batch, int ntok, int heads,
+                      int hd, void* stream) {
+    if (!A || !W || !qkv) return fail(VITK_ERR_INVALID, "vitk_qkv_proj_f32: null pointer");
+    if (batch <= 0 || ntok <= 0 || heads <= 0 || hd <= 0)
+        return fail(VITK_ERR_INVALID, "vitk_qkv_proj_f32: non-positive size");
+    return launched(launch_qkv_f32(A, W, bias, qkv, batch, ntok, heads, hd, reinterpret_cast<hipStream_t>(stream)),
+                    "vitk_qkv_proj_f32");
+}
+
+int vitk_patch_embed_f32(const float* img, const float* w, const float* bias, const float* cls, const float* pos,
+                         float* x, int batch, int img_h, int img_w, int patch, int D, void* stream) {
+    if (!img || !w || !bias || !cls || !pos || !x) return fail(VITK_ERR_INVALID, "vitk_patch_embed_f32: null pointer");
+    if (batch <= 0 || img_h <= 0 || img_w <= 0 || patch <= 0 || D <= 0)
+        return fail(VITK_ERR_INVALID, "vitk_patch_embed_f32: non-positive size");
+    if (!aligned16(cls) || !aligned16(pos) || !aligned16(x) || D % 4 != 0)
+        return fail(VITK_ERR_INVALID, "vitk_patch_embed_f32: cls/pos/x must be 16-byte aligned and D a multiple of 4");
+    const int gh = img_h / patch, gw = img_w / patch;   // Conv2d without padding floors
+    if (gh < 1 || gw < 1) return fail(VITK_ERR_INVALID, "vitk_patch_embed_f32: image smaller than one patch");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int rc = launched(launch_cls_pos(cls, pos, x, batch, gh * gw + 1, D, s), "vitk_patch_embed_f32(cls)");
+    if (rc) return rc;
+    return launched(launch_patch_f32(img, w, bias, pos, x, batch, img_h, img_w, patch, D, s), "vitk_patch_embed_f32");
+}
+
+int vitk_attention_f32(const float* q, const float* k, const float* v, float* ctx, int batch, int heads, int ntok,
+                       int hd, float scale, void* stream) {
+    if (!q || !k || !v || !ctx) return fail(VITK_ERR_INVALID, "vitk_attention_f32: null pointer");
+    if (batch <= 0 || heads <= 0 || ntok <= 0) return fail(VITK_ERR_INVALID, "vitk_attention_f32: non-positive size");
+    if (hd != 16 && hd != 32 && hd != 64 && hd != 80 && hd != 96 && hd != 128)
+        return fail(VITK_ERR_UNSUPPORTED, "vitk_attention_f32: hd=%d (16, 32, 64, 80, 96 and 128 are implemented)", hd);
+    if (ntok > 1024) return fail(VITK_ERR_UNSUPPORTED, "vitk_attention_f32: ntok=%d exceeds the LDS-resident limit 1024", ntok);
+    return launched(launch_attention_f32(q, k, v, ctx, batch, heads, ntok, hd, scale,
+                                         reinterpret_cast<hipStream_t>(stream)), "vitk_attention_f32");
 }
 
 }  // extern "C"

@@ -15,6 +15,9 @@ enum Epilogue {
     EPI_BIAS_TANH_BF16 = 6,  // out bf16 [M,N] = tanh(acc + bias)
 };
 
+// epilogues of the fp32-mode GEMM (f32path.hip)
+enum F32Epilogue { F32_BIAS = 0, F32_GELU = 1, F32_RESID = 2, F32_TANH = 3, F32_QKV = 4, F32_PATCH = 5 };
+
 struct GemmArgs {
     const void* A;       // bf16 activations [M,K] (row stride lda), or the bf16 image for the gather loader
     const void* W;       // bf16 weights [N,K], row-major
@@ -41,5 +44,14 @@ hipError_t launch_cast_f32_bf16(const float* in, void* out, int64_t n, hipStream
 int attention_max_tokens(int hd);
 hipError_t launch_attention(const void* q, const void* k, const void* v, void* out, int batch, int heads,
                             int ntok, int hd, float scale, int variant, hipStream_t s);
+
+hipError_t launch_gemm_f32(const float* A, const float* W, const float* bias, const float* resid, float* out, int M,
+                           int N, int K, int epilogue, hipStream_t s);
+hipError_t launch_qkv_f32(const float* A, const float* W, const float* bias, float* qkv, int batch, int ntok,
+                          int heads, int hd, hipStream_t s);
+hipError_t launch_patch_f32(const float* img, const float* w, const float* bias, const float* pos, float* x,
+                            int batch, int img_h, int img_w, int patch, int D, hipStream_t s);
+hipError_t launch_attention_f32(const float* q, const float* k, const float* v, float* out, int batch, int heads,
+                                int ntok, int hd, float scale, hipStream_t s);
 
 }  // namespace vitk

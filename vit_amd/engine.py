@@ -13,6 +13,7 @@ HBM layout of one forward (B images, N tokens, D channels, M = mlp width):
   qkv  bf16 [3, B, H, N, hd]  head-major q, k, v
   ctx  bf16 [B*N, D]      attention output, heads concatenated
   h    bf16 [B*N, M]      GELU(fc1) output
+In the fp32 compute mode (`precision="fp32"`) every buffer above is f32.
 """
 import torch
 
@@ -26,9 +27,13 @@ def _bf16(t):
 
 
 class WeightCache:
-    def __init__(self, model):
+    """Kernel-ready weights.  `fp32=True` (the fp32 compute mode) keeps the GEMM weights in f32: they are
+    then the parameters themselves, not copies."""
+
+    def __init__(self, model, fp32=False):
         self._model = model
         self._key = None
+        self._fp32 = fp32
         self.t = {}
 
     def _signature(self):
@@ -45,6 +50,7 @@ class WeightCache:
         m = self._model
         t = {}
         D = m.hidden_size
+        _bf16 = _f32 if self._fp32 else globals()["_bf16"]       # GEMM weight dtype of this mode
         t["embed.w"] = _bf16(m.embedding.weight).reshape(D, -1)          # OIHW flattened: k = c*P*P + i*P + j
         t["embed.b"] = _f32(m.embedding.bias)
         t["cls"] = _f32(m.cls_token).reshape(D)
@@ -70,8 +76,9 @@ class WeightCache:
 class Workspace:
     """Activation buffers for one (B, N, D, H, M, classes) shape on one device."""
 
-    def __init__(self, device, B, N, D, H, M, ncls):
-        bf, f32 = torch.bfloat16, torch.float32
+    def __init__(self, device, B, N, D, H, M, ncls, fp32=False):
+        bf, f32 = (torch.float32 if fp32 else torch.bfloat16), torch.float32      # bf = GEMM operand dtype
+        self.fp32 = fp32
         hd = D // H
         e = lambda *s, dtype: torch.empty(*s, dtype=dtype, device=device)   # noqa: E731
         self.shape = (B, N, D, H, M, ncls)

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvitk.so")
 
 VITK_F32, VITK_BF16 = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int
@@ -28,7 +28,12 @@ SIGNATURES = {
     "vitk_gemm_bias_residual": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     "vitk_qkv_proj": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "vitk_attention": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
+    "vitk_gemm_f32": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "vitk_qkv_proj_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "vitk_patch_embed_f32": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "vitk_attention_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
 }
+EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_TANH = 0, 1, 2, 3      # vitk_gemm_f32 epilogues (include/vitk.h)
 EXPORTS = sorted(list(SIGNATURES) + ["vitk_version", "vitk_last_error", "vitk_set_debug_variant"])
 
 _lib = None

@@ -181,3 +181,65 @@ def attention(qkv, ctx, scale):
         _lib.check(L.vitk_attention(_ptr(qkv[0]), _ptr(qkv[1]), _ptr(qkv[2]), _ptr(ctx), B, H, N, hd,
                                     float(scale), _stream()), L)
     return ctx
+
+
+# ---- fp32 compute mode (vitk_*_f32) ------------------------------------------------------------
+
+def gemm_f32(a, w, bias, out, epilogue=_lib.EPI_BIAS, resid=None):
+    """out f32 [M,N] = epilogue(a @ w.T + bias); a f32 [M,K], w f32 [N,K]."""
+    L = _lib.load()
+    for n, t in (("A", a), ("W", w), ("bias", bias), ("resid", resid), ("out", out)):
+        _chk(t, torch.float32, n)
+    M, N, K = _dense_shapes(a, w, out, "gemm_f32")
+    if resid is not None and tuple(resid.shape) != (M, N):
+        raise _lib.VitkError(f"gemm_f32: resid {tuple(resid.shape)} vs out [{M},{N}]")
+    with _span("gemm_f32"):
+        _lib.check(L.vitk_gemm_f32(_ptr(a), _ptr(w), _ptr(bias), _ptr(resid), _ptr(out), M, N, K, int(epilogue),
+                                   _stream()), L)
+    return out
+
+
+def qkv_proj_f32(a, w, bias, qkv, batch, ntok, heads, hd):
+    """a f32 [batch*ntok, D]; qkv f32 [3, batch, heads, ntok, hd]."""
+    L = _lib.load()
+    for n, t in (("A", a), ("W", w), ("bias", bias), ("qkv", qkv)):
+        _chk(t, torch.float32, n)
+    D = heads * hd
+    if tuple(a.shape) != (batch * ntok, D) or tuple(w.shape) != (3 * D, D) or \
+            tuple(qkv.shape) != (3, batch, heads, ntok, hd):
+        raise _lib.VitkError(f"qkv_proj_f32: shapes A{tuple(a.shape)} W{tuple(w.shape)} qkv{tuple(qkv.shape)}")
+    with _span("qkv_proj_f32"):
+        _lib.check(L.vitk_qkv_proj_f32(_ptr(a), _ptr(w), _ptr(bias), _ptr(qkv), batch, ntok, heads, hd, _stream()), L)
+    return qkv
+
+
+def patch_embed_f32(img, w, bias, cls, pos, out, patch):
+    """img f32 [B,3,H,W]; w f32 [D,3*P*P]; out f32 [B,ntok,D]."""
+    L = _lib.load()
+    for n, t in (("img", img), ("w", w), ("bias", bias), ("cls", cls), ("pos", pos), ("out", out)):
+        _chk(t, torch.float32, n)
+    B, C, H, W = img.shape
+    D = w.shape[0]
+    if C != 3 or w.shape[1] != 3 * patch * patch:
+        raise _lib.VitkError(f"patch_embed_f32: weight {tuple(w.shape)} does not match 3x{patch}x{patch} patches")
+    ntok = (H // patch) * (W // patch) + 1
+    if tuple(out.shape) != (B, ntok, D) or pos.numel() != ntok * D:
+        raise _lib.VitkError(f"patch_embed_f32: out {tuple(out.shape)} / pos {tuple(pos.shape)} do not match "
+                             f"[{B},{ntok},{D}]")
+    with _span("patch_embed_f32"):
+        _lib.check(L.vitk_patch_embed_f32(_ptr(img), _ptr(w), _ptr(bias), _ptr(cls), _ptr(pos), _ptr(out),
+                                          B, H, W, patch, D, _stream()), L)
+    return out
+
+
+def attention_f32(qkv, ctx, scale):
+    """qkv f32 [3, B, H, N, hd] -> ctx f32 [B, N, H*hd]."""
+    L = _lib.load()
+    _chk(qkv, torch.float32, "qkv"); _chk(ctx, torch.float32, "ctx")
+    _, B, H, N, hd = qkv.shape
+    if tuple(ctx.shape) != (B, N, H * hd):
+        raise _lib.VitkError(f"attention_f32: ctx {tuple(ctx.shape)} vs [{B},{N},{H * hd}]")
+    with _span("attention_f32"):
+        _lib.check(L.vitk_attention_f32(_ptr(qkv[0]), _ptr(qkv[1]), _ptr(qkv[2]), _ptr(ctx), B, H, N, hd,
+                                        float(scale), _stream()), L)
+    return ctx

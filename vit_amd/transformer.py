@@ -14,12 +14,13 @@ Data flow of one block (models/transformer.py:66-76), x = fp32 residual stream:
     y   = LN2(x)                      -> bf16        vitk_layernorm
     h   = gelu(y W_1^T + b)           -> bf16        vitk_gemm_bias_gelu
     x   = x + h W_2^T + b             -> fp32        vitk_gemm_bias_residual
+In the fp32 compute mode the same flow runs on f32 buffers through vitk_*_f32.
 """
 import torch
 import torch.nn as nn
 
 from . import ops
-from .lib import VitkError
+from .lib import EPI_GELU, EPI_RESIDUAL, VitkError
 
 
 def _eps_of(norm_module):
@@ -42,6 +43,10 @@ class MLPBlock(nn.Module):
 
     def fused(self, y16, x, h16, w, p):
         """x += fc2(gelu(fc1(y16)))  (rows = tokens); h16 is the [rows, hidden] scratch."""
+        if y16.dtype == torch.float32:                       # fp32 compute mode
+            ops.gemm_f32(y16, w[p + "fc1.w"], w[p + "fc1.b"], h16, EPI_GELU)
+            ops.gemm_f32(h16, w[p + "fc2.w"], w[p + "fc2.b"], x, EPI_RESIDUAL, resid=x)
+            return
         ops.gemm_bias_gelu(y16, w[p + "fc1.w"], w[p + "fc1.b"], h16)
         ops.gemm_bias_residual(h16, w[p + "fc2.w"], w[p + "fc2.b"], x, x)
 
@@ -61,6 +66,11 @@ class Attention(nn.Module):
     def fused(self, y16, x, qkv, ctx, w, p):
         """x += out_proj(attention(in_proj(y16))); qkv/ctx are scratch buffers."""
         _, B, H, N, hd = qkv.shape
+        if y16.dtype == torch.float32:                       # fp32 compute mode
+            ops.qkv_proj_f32(y16, w[p + "qkv.w"], w[p + "qkv.b"], qkv, B, N, H, hd)
+            ops.attention_f32(qkv, ctx, self.scaling)
+            ops.gemm_f32(ctx.view(B * N, H * hd), w[p + "out.w"], w[p + "out.b"], x, EPI_RESIDUAL, resid=x)
+            return
         ops.qkv_proj(y16, w[p + "qkv.w"], w[p + "qkv.b"], qkv, B, N, H, hd)
         ops.attention(qkv, ctx, self.scaling)
         ops.gemm_bias_residual(ctx.view(B * N, H * hd), w[p + "out.w"], w[p + "out.b"], x, x)

@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from . import ops
 from .engine import WeightCache, Workspace
-from .lib import VitkError
+from .lib import EPI_TANH, VitkError
 from .transformer import Encoder
 
 
@@ -27,6 +27,11 @@ class VisionTransformer(nn.Module):
                  dropout=0., attn_bias=True, attn_scaling=None, attn_dropout=0.,
                  norm=nn.LayerNorm, pre_logits=True, *args, **kwargs):
         super().__init__()
+        # The one keyword beyond the reference's: precision="bf16" (default: bf16 MFMA operands, fp32
+        # accumulation and residual stream) or "fp32" (every op in f32, as the reference computes with
+        # fp32 parameters).  Also settable later with set_precision().
+        self.precision = "bf16"
+        self.set_precision(kwargs.get("precision", "bf16"))
         self.num_classes = num_classes
         self.hidden_size = hidden_size
         self.patches = patches
@@ -47,8 +52,17 @@ class VisionTransformer(nn.Module):
 
         self.apply(self._init)
         # not part of state_dict: kernel-ready weights and activation buffers
-        self._cache = WeightCache(self)
+        self._cache = WeightCache(self, fp32=self.precision == "fp32")
         self._ws = {}
+
+    def set_precision(self, precision):
+        if precision not in ("bf16", "fp32"):
+            raise VitkError(f"precision must be 'bf16' or 'fp32', got {precision!r}")
+        if precision != self.precision or not hasattr(self, "_cache"):
+            self.precision = precision
+            self._cache = WeightCache(self, fp32=precision == "fp32")
+            self._ws = {}
+        return self
 
     def _init(self, module):
         # same draws as the reference (:34-43); `embedding` keeps Conv2d's default init there too
@@ -70,7 +84,7 @@ class VisionTransformer(nn.Module):
         if ws is None:
             if len(self._ws) >= 4:      # keep at most a few shapes resident
                 self._ws.clear()
-            ws = self._ws[key] = Workspace(device, B, N, D, H, M, self.num_classes)
+            ws = self._ws[key] = Workspace(device, B, N, D, H, M, self.num_classes, fp32=self.precision == "fp32")
         return ws
 
     def forward(self, x):
@@ -92,6 +106,17 @@ class VisionTransformer(nn.Module):
             raise VitkError(f"input {Hi}x{Wi} gives {N} tokens but pos_embed holds {w['pos'].shape[0]}")
         ws = self._workspace(x.device, B, N)
         out_dtype = self.head.weight.dtype
+
+        if self.precision == "fp32":
+            if x.dtype not in (torch.float32, torch.bfloat16):
+                raise VitkError(f"unsupported image dtype {x.dtype}")
+            ops.patch_embed_f32(x.float().contiguous(), w["embed.w"], w["embed.b"], w["cls"], w["pos"], ws.x, P)
+            feat = self.encoder.fused(ws, w)
+            if "pre.w" in w:
+                ops.gemm_f32(feat, w["pre.w"], w["pre.b"], ws.pre, EPI_TANH)
+                feat = ws.pre
+            ops.gemm_f32(feat, w["head.w"], w["head.b"], ws.logits)
+            return ws.logits.to(out_dtype, copy=True)
 
         if x.dtype == torch.bfloat16:
             img16 = x.contiguous()

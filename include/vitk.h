@@ -50,8 +50,10 @@ const char* vitk_last_error(void);
  *   Timing probes, which produce WRONG OR NO RESULTS: order bits 17-19 on the bias -> bf16 epilogue of
  *   the default kernel (1 = no DMA, 2 = no epilogue, 3 = accumulator clearing instead of the zero C
  *   operand, 7 = cycle stamps written over out[0..]), order bit 22 = bf16 epilogues without stores.
- * attention_variant: bit 0 = V stored transposed in LDS instead of transposed LDS reads; bits 2-3 =
- *   timing probes (wrong results).
+ * attention_variant, low 2 bits: 0 = automatic (whole K/V of a head resident in LDS with transposed LDS
+ *   reads when they fit: ntok <= 608 at head_dim 64, 288 at 96; else streamed), 1 = resident with V stored
+ *   transposed (head_dim 64), 2 = K/V streamed through LDS in 64-key chunks; bit 3 = timing probe
+ *   without the key loop (wrong results).
  * Process-global; apart from the probes, results are identical across variants up to fp32 summation
  * order. */
 void vitk_set_debug_variant(int gemm_variant, int attention_variant);
@@ -102,8 +104,8 @@ int vitk_qkv_proj(const void* A, const void* W, const float* bias, void* qkv, in
                   int hd, void* stream);
 
 /* ctx[b, t, h*hd + e] = sum_s softmax_s(q[b,h,t,:] . k[b,h,s,:] * scale) * v[b,h,s,e]
- * q, k, v: bf16 [batch, heads, ntok, hd]; ctx: bf16 [batch, ntok, heads*hd].  hd == 64 with ntok <= 608, or hd == 96 with
- * ntok <= 288 (K and V of one head stay resident in LDS); other head sizes return VITK_ERR_UNSUPPORTED.
+ * q, k, v: bf16 [batch, heads, ntok, hd]; ctx: bf16 [batch, ntok, heads*hd].  hd == 64 or 96 (K and V stream
+ * through LDS in 64-key chunks, ntok <= 16384); other head sizes return VITK_ERR_UNSUPPORTED.
  * Replaces q@k^T, scaling, softmax, @v, transpose, reshape at models/transformer.py:43-46. */
 int vitk_attention(const void* q, const void* k, const void* v, void* ctx, int batch, int heads, int ntok,
                    int hd, float scale, void* stream);

@@ -37,7 +37,7 @@ def test_argument_errors_are_reported_not_launched():
     assert L.vitk_layernorm(p, 700, p, p, p, 700, 4, 700, 1e-6, 1, None) == 2      # D not supported
     assert L.vitk_attention(p, p, p, p, 1, 1, 197, 80, 0.1, None) == 2             # head_dim 80
     assert b"hd=80" in L.vitk_last_error()
-    assert L.vitk_attention(p, p, p, p, 1, 1, 700, 64, 0.1, None) == 2             # too many tokens
+    assert L.vitk_attention(p, p, p, p, 1, 1, 20000, 64, 0.1, None) == 2           # too many tokens
     assert L.vitk_gemm_bias_gelu(p, p, p, p, 16, 16, 40, None) == 2                # K % 32
     assert L.vitk_gemm_bias(p, p, p, p, 16, 16, 64, 7, None) == 2                  # dtype code
     assert L.vitk_gemm_bias_residual(p, p, p, None, p, 16, 16, 64, None) == 1

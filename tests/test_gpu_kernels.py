@@ -157,9 +157,9 @@ def _attn_ref(q, k, v, scale):
     return o.transpose(1, 2).reshape(B, N, H * hd).float()
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("B,H,N", [(2, 12, 197), (1, 12, 577), (3, 2, 1), (2, 3, 32), (2, 3, 33), (1, 4, 224),
-                                   (1, 2, 225), (2, 16, 197), (1, 1, 608)])
+                                   (1, 2, 225), (2, 16, 197), (1, 1, 608), (2, 2, 64), (2, 2, 65), (1, 2, 129)])
 def test_attention(B, H, N, variant):
     _attention_case(B, H, N, 64, variant)
 
@@ -169,7 +169,19 @@ def test_attention_head_dim_96(B, H, N):
     _attention_case(B, H, N, 96, 0)
 
 
+@pytest.mark.parametrize("N,hd", [(1025, 64), (785, 96), (609, 64), (289, 96)])
+def test_attention_long_sequences_stream_through_lds(N, hd):
+    _attention_case(1, 2, N, hd, 0)
+
+
+@pytest.mark.parametrize("N,hd", [(197, 96), (577, 64), (33, 64)])
+def test_attention_forced_streaming(N, hd):
+    _attention_case(2, 3, N, hd, 2)
+
+
 def _attention_case(B, H, N, hd, variant):
+    if variant == 1 and N > 608:
+        pytest.skip("resident K/V needs ntok <= 608")
     lib.load().vitk_set_debug_variant(0, variant)
     qkv = to16(rnd(3, B, H, N, hd, seed=N + variant))
     want = _attn_ref(qkv[0].float(), qkv[1].float(), qkv[2].float(), hd ** -0.5)
@@ -179,7 +191,7 @@ def _attention_case(B, H, N, hd, variant):
     assert torch.allclose(f32(ctx), want, rtol=2e-2, atol=6e-3)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_attention_online_softmax_rescale_is_exercised(variant):
     """A key far down the sequence dominates: the running max jumps in a late key block, so every
     earlier partial sum must be rescaled.  Scores of ~+-60 also check the exp2 argument handling."""

@@ -37,53 +37,70 @@ static int g_attn_probe = 0;   // timing probe (debug variant bit 2): all workgr
 //   HD 96: K c ^ (r & 15),       V c ^ ((r & 3) << 2)        in 256-byte rows (12 of 16 slots used),
 // which makes the ds_read_b128 of 32 rows x one chunk column (K) and the transposed read of 4 rows x 64 B
 // (V) conflict-free in both geometries.
-template <int HD, int NW, bool VTR>
+//
+// STREAM = false: the head's whole K and V are staged once (any of the staging variants).
+// STREAM = true (VTR only): K and V pass through LDS in chunks of 64 keys, double-buffered: while the
+// waves work on chunk c, the LDS-DMA of chunk c+1 is in flight; one barrier per chunk.  32 KiB (64 KiB at
+// head_dim 96) of LDS per workgroup whatever the token count, so several workgroups share a CU and the
+// first MFMA waits for 16 KiB instead of the whole head.
+template <int HD, int NW, bool VTR, bool STREAM>
 __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restrict__ Q,
                                                          const bf16_t* __restrict__ K,
                                                          const bf16_t* __restrict__ V,
                                                          bf16_t* __restrict__ O, int ntok, int heads,
                                                          float scale_log2e, int probe) {
     static_assert(HD == 64 || (HD == 96 && VTR), "head_dim 64, or 96 with transposed LDS reads");
+    static_assert(VTR || !STREAM, "streaming needs the transposed LDS reads");
     constexpr int KS = HD / 16;                  // k-steps of q k^T
     constexpr int DB = HD / 32;                  // 32-row blocks of O^T
     constexpr int RB = HD == 64 ? 128 : 256;     // bytes per K/V row in LDS
     constexpr int RPP = 1024 / RB;               // rows per LDS-DMA piece (one wave instruction = 1 KiB)
     constexpr int CPR = RB / 16;                 // 16-byte slots per LDS row
+    constexpr int KC = 64;                       // keys per streamed chunk
+    constexpr int CHUNK = 2 * KC * RB;           // bytes of one chunk buffer: K rows, then V rows
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int bh = (probe & 1) ? 0 : blockIdx.x;   // image * heads + head (probe: every workgroup reads head 0)
+    const int bh = blockIdx.x;                     // image * heads + head
     const int kblocks = (ntok + 31) >> 5;
     const int kpad = kblocks * 32;
     const int vts = kpad + 4;    // V^T row stride in elements (VTR = false)
 
-    char* k_lds = smem;
-    char* v_lds = smem + kpad * RB;
+    const char* k_lds = smem;                      // STREAM: re-pointed at the current chunk buffer
+    const char* v_lds = smem + (STREAM ? KC : kpad) * RB;
 
-    // ---- stage K and V of this head
     auto k_swz = [](int row) { return HD == 64 ? ((row >> 1) & 7) : (row & 15); };
     auto v_swz = [](int row) { return HD == 64 ? (((row >> 1) & 1) << 2) : ((row & 3) << 2); };
     const bf16_t* kg = K + (size_t)bh * ntok * HD;
     const bf16_t* vg = V + (size_t)bh * ntok * HD;
-    if constexpr (VTR) {
-        // LDS-DMA: one wave instruction moves 1 KiB = RPP LDS rows; LDS is written linearly, so the slot
-        // XOR is applied to each lane's SOURCE chunk.  Rows past ntok re-read the last row (finite
-        // values: such keys are masked out of the softmax, and their P is 0 in P.V); at head_dim 96 the
-        // slots whose chunk would be 12..15 re-read chunk 11 and are never read back.
-        const int pieces = kpad / RPP;                       // per operand
+
+    // LDS-DMA of `pieces` K pieces followed by `pieces` V pieces (RPP rows each) starting at key row
+    // `row0`, into `dst`.  One wave instruction moves 1 KiB; LDS is written linearly, so the slot XOR is
+    // applied to each lane's SOURCE chunk.  Rows past ntok re-read the last row (finite values: such keys
+    // are masked out of the softmax, and their P is 0 in P.V); at head_dim 96 the slots whose chunk would
+    // be 12..15 re-read chunk 11 and are never read back.
+    auto stage = [&](char* dst, int row0, int pieces) {
         for (int pi = wave; pi < 2 * pieces; pi += NW) {     // wave-uniform
             const bool is_v = pi >= pieces;
-            const int row = (is_v ? pi - pieces : pi) * RPP + lane / CPR;
+            const int lrow = (is_v ? pi - pieces : pi) * RPP + lane / CPR;
             const int slot = lane % CPR;
-            int c = is_v ? slot ^ v_swz(row) : slot ^ k_swz(row);
+            int c = is_v ? slot ^ v_swz(lrow) : slot ^ k_swz(lrow);     // row0 is a multiple of 64: same swizzle
             c = c < HD / 8 ? c : HD / 8 - 1;
-            const int grow = row < ntok ? row : ntok - 1;
+            const int grow = row0 + lrow < ntok ? row0 + lrow : ntok - 1;
             const bf16_t* src = (is_v ? vg : kg) + (size_t)grow * HD + c * 8;
-            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(smem + pi * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(dst + pi * 1024), 16, 0, 0);
         }
+    };
+
+    if constexpr (STREAM) {
+        stage(smem, 0, KC / RPP);
+    } else if constexpr (VTR) {
+        stage(smem, 0, kpad / RPP);
     } else if constexpr (HD == 64) {
+        char* kw = smem;
+        char* vw = smem + kpad * RB;
         for (int cid = tid; cid < kpad * 8; cid += NW * 64) {
             const int row = cid >> 3, c = cid & 7;
             u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
@@ -91,8 +108,8 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
                 kv = *reinterpret_cast<const u32x4*>(kg + (size_t)row * HD + c * 8);
                 vv = *reinterpret_cast<const u32x4*>(vg + (size_t)row * HD + c * 8);
             }
-            *reinterpret_cast<u32x4*>(k_lds + row * RB + ((c ^ ((row >> 1) & 7)) << 4)) = kv;
-            unsigned short* vt = reinterpret_cast<unsigned short*>(v_lds);
+            *reinterpret_cast<u32x4*>(kw + row * RB + ((c ^ ((row >> 1) & 7)) << 4)) = kv;
+            unsigned short* vt = reinterpret_cast<unsigned short*>(vw);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 vt[(c * 8 + 2 * j) * vts + row] = (unsigned short)(vv[j] & 0xFFFFu);
@@ -101,25 +118,29 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
         }
     }
 
-    // ---- this wave's 32 query rows: B-operand fragments straight from global memory.
+    // ---- this wave's 32 query rows (B-operand fragments straight from global memory).  With resident K/V a
+    // wave works through q-tiles wave, wave + NW, ... of the head; with streamed K/V it has the one q-tile
+    // (blockIdx.y * NW + wave).
     const int r = lane & 31, hh = lane >> 5;
-    const int q0 = (blockIdx.y * NW + wave) * 32;
-    const int qrow = q0 + r;
-    const int qld = qrow < ntok ? qrow : ntok - 1;   // padded rows re-read the last row; never stored
+    int q0 = (STREAM ? blockIdx.y * NW + wave : wave) * 32;
+    int qrow = q0 + r;
     bf16x8 qf[KS];
-    {
+    auto load_q = [&]() {
+        const int qld = qrow < ntok ? qrow : ntok - 1;   // padded rows re-read the last row; never stored
         const bf16_t* qg = Q + ((size_t)bh * ntok + qld) * HD + hh * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qg + ks * 16);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed
-    __syncthreads();
+    };
+    load_q();
 
     f32x16 o_acc[DB];
+    auto clear_o = [&]() {
 #pragma unroll
-    for (int d = 0; d < DB; ++d)
+        for (int d = 0; d < DB; ++d)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) o_acc[d][i] = 0.f;
+            for (int i = 0; i < 16; ++i) o_acc[d][i] = 0.f;
+    };
+    clear_o();
     // Online softmax with a lazy running max (log2 units): the accumulators are rescaled only when a
     // block's max exceeds the running one by more than kLazy, so probabilities stay below 2^kLazy
     // (exact in fp32 sums, same relative rounding in bf16) and most blocks skip the 32-register rescale.
@@ -131,9 +152,10 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
     const int tsub = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
     const bool ragged = (ntok & 31) != 0;
 
-    // One step of the key loop over NB (1 or 2) blocks of 32 keys.  Two blocks give two independent
-    // MFMA chains and share one max exchange and one rescale decision.
-    auto key_step = [&](int kb, auto nb_c) {
+    // One step of the key loop over NB (1 or 2) blocks of 32 keys: two blocks give two independent MFMA
+    // chains and share one max exchange and one rescale decision.  lb = first block's index in the LDS
+    // image (k_lds / v_lds), gb = its index in the sequence.
+    auto key_step = [&](int lb, int gb, auto nb_c) {
         constexpr int NB = decltype(nb_c)::value;
         f32x16 s[NB];
 #pragma unroll
@@ -146,13 +168,13 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
-                const char* krow = k_lds + ((kb + u) * 32 + r) * RB;
+                const char* krow = k_lds + ((lb + u) * 32 + r) * RB;
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + (((ks * 2 + hh) ^ kswz) << 4));
                 s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[u], 0, 0, 0);
             }
         }
-        if (ragged && kb + NB == kblocks) {     // wave-uniform: keys past ntok exist only in the last block
-            const int key0 = (kb + NB - 1) * 32 + 4 * hh;
+        if (ragged && gb + NB == kblocks) {     // wave-uniform: keys past ntok exist only in the last block
+            const int key0 = (gb + NB - 1) * 32 + 4 * hh;
 #pragma unroll
             for (int i = 0; i < 16; ++i)
                 if (key0 + (i & 3) + 8 * (i >> 2) >= ntok) s[NB - 1][i] = kMaskedScore;
@@ -204,7 +226,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
 #pragma unroll
                 for (int d = 0; d < DB; ++d) {
                     bf16x4 v0, v1;
-                    const int keyb = (kb + u) * 32 + 16 * st + 4 * hh;   // + 8t + (0..3)
+                    const int keyb = (lb + u) * 32 + 16 * st + 4 * hh;   // + 8t + (0..3)
                     if constexpr (VTR) {
                         const int chunk = d * 4 + tsub * 2 + (tp >> 1);
                         const int ka = keyb + tq, kb2 = keyb + 8 + tq;
@@ -223,14 +245,12 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
             }
         }
     };
+    using C1 = std::integral_constant<int, 1>;
+    using C2 = std::integral_constant<int, 2>;
+    const int kend = (probe & 2) ? 0 : kblocks;      // probe bit 1: skip the key loop (timing only)
 
-    if (q0 < ntok) {   // wave-uniform: a wave whose whole q-tile is padding only took part in staging
-        int kb = 0;
-        const int kend = (probe & 2) ? 0 : kblocks;      // probe bit 1: skip the key loop (timing only)
-        for (; kb + 2 <= kend; kb += 2) key_step(kb, std::integral_constant<int, 2>{});
-        if (kb < kend) key_step(kb, std::integral_constant<int, 1>{});
-
-        // ---- normalise and store: lane holds q = qrow, d = 32*blk + 8g + 4*hh + (0..3)
+    // normalise and store one q-tile: lane holds q = qrow, d = 32*blk + 8g + 4*hh + (0..3)
+    auto finish = [&]() {
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = 1.0f / l_tot;
         if (qrow < ntok) {
@@ -245,63 +265,119 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
                     *reinterpret_cast<u32x2*>(og + d * 32 + 8 * g) = pk;
                 }
         }
+    };
+
+    if constexpr (STREAM) {
+        const bool active = q0 < ntok;   // wave-uniform: a wave whose whole q-tile is padding only takes part in staging
+        const int nchunks = (kblocks + 1) >> 1;
+        for (int c = 0; c < nchunks; ++c) {
+            // chunk c has landed (every wave waits for its own pieces, the barrier publishes them), and
+            // every wave is done reading chunk c-1, whose buffer chunk c+1 now overwrites
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (c + 1 < nchunks) stage(smem + ((c + 1) & 1) * CHUNK, (c + 1) * KC, KC / RPP);
+            k_lds = smem + (c & 1) * CHUNK;
+            v_lds = k_lds + KC * RB;
+            if (active && 2 * c < kend) {
+                if (2 * c + 2 <= kend) key_step(0, 2 * c, C2{});
+                else key_step(0, 2 * c, C1{});
+            }
+        }
+        if (active) finish();
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed
+        __syncthreads();
+        while (q0 < ntok) {                                // wave-uniform
+            int kb = 0;
+            for (; kb + 2 <= kend; kb += 2) key_step(kb, kb, C2{});
+            if (kb < kend) key_step(kb, kb, C1{});
+            finish();
+            q0 += NW * 32;
+            qrow = q0 + r;
+            if (q0 < ntok) {
+                load_q();
+                clear_o();
+                m_run = kMaskedScore;
+                l_run = 0.f;
+            }
+        }
     }
 }
 
-template <int HD, int NW, bool VTR>
+template <int HD, int NW, bool VTR, bool STREAM>
 static hipError_t attn_launch(const void* q, const void* k, const void* v, void* out, int batch, int heads,
                               int ntok, float scale, hipStream_t s) {
     const int kpad = ((ntok + 31) / 32) * 32;
     const int rb = HD == 64 ? 128 : 256;
-    const size_t lds = VTR ? (size_t)kpad * rb * 2 : (size_t)kpad * 128 + (size_t)64 * (kpad + 4) * 2;
+    const size_t lds = STREAM ? (size_t)4 * 64 * rb
+                              : VTR ? (size_t)kpad * rb * 2 : (size_t)kpad * 128 + (size_t)64 * (kpad + 4) * 2;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {   // beyond the default dynamic-LDS limit the kernel must be told
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_fwd<HD, NW, VTR>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_fwd<HD, NW, VTR, STREAM>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     const int qtiles = (ntok + 31) / 32;
-    dim3 grid(batch * heads, (qtiles + NW - 1) / NW), block(NW * 64);
-    hipLaunchKernelGGL((attention_fwd<HD, NW, VTR>), grid, block, lds, s,
+    dim3 grid(batch * heads, STREAM ? (qtiles + NW - 1) / NW : 1), block(NW * 64);
+    hipLaunchKernelGGL((attention_fwd<HD, NW, VTR, STREAM>), grid, block, lds, s,
                        reinterpret_cast<const bf16_t*>(q), reinterpret_cast<const bf16_t*>(k),
                        reinterpret_cast<const bf16_t*>(v), reinterpret_cast<bf16_t*>(out), ntok, heads,
                        scale * 1.44269504088896340736f, g_attn_probe);
     return hipGetLastError();
 }
 
-// token counts whose K and V fit the 160 KiB of LDS: 608 at head_dim 64, 288 at head_dim 96
-int attention_max_tokens(int hd) { return hd == 64 ? 608 : hd == 96 ? 288 : 0; }
+// token counts the kernels take: any with the streamed K/V; the resident variants need K and V of one
+// head in the 160 KiB of LDS (608 tokens at head_dim 64, 288 at head_dim 96)
+int attention_max_tokens(int hd) { return (hd == 64 || hd == 96) ? 16384 : 0; }
 
 hipError_t launch_attention(const void* q, const void* k, const void* v, void* out, int batch, int heads,
                             int ntok, int hd, float scale, int variant, hipStream_t s) {
     if ((hd != 64 && hd != 96) || ntok < 1) return hipErrorInvalidValue;
     const int qtiles = (ntok + 31) / 32;
-    // Waves per workgroup (one 32-row q-tile each): a single workgroup per head when the
-    // q-tiles fit 7 waves (K/V staged once), else the width that leaves the fewest idle
-    // wave slots, larger on ties.
-    const bool tr = (variant & 1) == 0 || hd != 64;
+    // variant: 0 = automatic (K/V resident in LDS with transposed reads when they fit, else streamed in
+    // 64-key chunks); 1 = resident, V stored transposed (head_dim 64); 2 = streamed
+    int mode = variant & 3;
+    const bool fits = ntok <= (hd == 64 ? 608 : 288);
+    if (mode == 3 || (mode == 1 && (hd != 64 || !fits))) return hipErrorInvalidValue;
+    if (mode == 0 && !fits) mode = 2;
     g_attn_probe = (variant >> 2) & 3;
+    // Waves per workgroup (one 32-row q-tile at a time each).  Resident K/V: one workgroup per head, its
+    // waves take q-tiles round-robin; the width with the best balance (q-tiles / (rounds * waves)), the
+    // larger on ties.  Streamed: one q-tile per wave, fewest workgroups per head, then fewest idle slots.
     int nw = 4;
-    if (qtiles > 4 && qtiles <= 7) {
+    if (mode != 2) {
+        long best = -1;
+        for (int c : {4, 5, 6, 7, 8, 10}) {
+            const int rounds = (qtiles + c - 1) / c;
+            const long util = 1000L * qtiles / (rounds * c);
+            if (util >= best) { best = util; nw = c; }
+        }
+    } else if (qtiles > 4 && qtiles <= 7) {
         nw = 7;
     } else if (qtiles > 7) {
-        int best = 1 << 30;
+        int best_wgs = 1 << 30, best_idle = 1 << 30;
         for (int c = 4; c <= 8; ++c) {
-            const int idle = ((qtiles + c - 1) / c) * c - qtiles;
-            if (idle <= best) { best = idle; nw = c; }
+            const int wgs = (qtiles + c - 1) / c, idle = wgs * c - qtiles;
+            if (wgs < best_wgs || (wgs == best_wgs && idle < best_idle)) { best_wgs = wgs; best_idle = idle; nw = c; }
         }
     }
-#define VITK_ATTN_CASE(NWV)                                                                        \
-    case NWV:                                                                                      \
-        if (hd == 96) return attn_launch<96, NWV, true>(q, k, v, out, batch, heads, ntok, scale, s); \
-        return tr ? attn_launch<64, NWV, true>(q, k, v, out, batch, heads, ntok, scale, s)         \
-                  : attn_launch<64, NWV, false>(q, k, v, out, batch, heads, ntok, scale, s);
+#define VITK_ATTN_CASE(NWV)                                                                                   \
+    case NWV:                                                                                                 \
+        if (hd == 96 && mode == 2) return attn_launch<96, NWV, true, true>(q, k, v, out, batch, heads, ntok, scale, s);  \
+        if (hd == 96) return attn_launch<96, NWV, true, false>(q, k, v, out, batch, heads, ntok, scale, s);   \
+        if (mode == 2) return attn_launch<64, NWV, true, true>(q, k, v, out, batch, heads, ntok, scale, s);   \
+        if (mode == 0) return attn_launch<64, NWV, true, false>(q, k, v, out, batch, heads, ntok, scale, s);  \
+        return attn_launch<64, NWV, false, false>(q, k, v, out, batch, heads, ntok, scale, s);
     switch (nw) {
         VITK_ATTN_CASE(4)
         VITK_ATTN_CASE(5)
         VITK_ATTN_CASE(6)
         VITK_ATTN_CASE(7)
         VITK_ATTN_CASE(8)
+        case 10:      // resident modes only
+            if (hd == 96) return attn_launch<96, 10, true, false>(q, k, v, out, batch, heads, ntok, scale, s);
+            if (mode == 0) return attn_launch<64, 10, true, false>(q, k, v, out, batch, heads, ntok, scale, s);
+            return attn_launch<64, 10, false, false>(q, k, v, out, batch, heads, ntok, scale, s);
     }
 #undef VITK_ATTN_CASE
     return hipErrorInvalidValue;

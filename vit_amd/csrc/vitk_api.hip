@@ -173,7 +173,7 @@ int vitk_attention(const void* q, const void* k, const void* v, void* ctx, int b
         return fail(VITK_ERR_INVALID, "vitk_attention: pointers must be 16-byte aligned");
     if (hd != 64 && hd != 96) return fail(VITK_ERR_UNSUPPORTED, "vitk_attention: hd=%d (64 and 96 are implemented)", hd);
     if (ntok > attention_max_tokens(hd))
-        return fail(VITK_ERR_UNSUPPORTED, "vitk_attention: ntok=%d exceeds the LDS-resident limit %d at hd=%d", ntok,
+        return fail(VITK_ERR_UNSUPPORTED, "vitk_attention: ntok=%d exceeds the limit %d at hd=%d", ntok,
                     attention_max_tokens(hd), hd);
     return launched(launch_attention(q, k, v, ctx, batch, heads, ntok, hd, scale, g_attn_variant,
                                      reinterpret_cast<hipStream_t>(stream)),

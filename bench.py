@@ -90,9 +90,19 @@ def main():
                     help="compute mode; the headline metric is bf16, fp32 is the reference-accuracy mode")
     a = ap.parse_args()
 
-    rank, world, local = vdist.init_from_env()
+    # Rehearsal switches for a box with fewer GPUs than ranks (never set by the real launch): the ranks
+    # then share GPU (local % count) and talk over gloo, since RCCL refuses two ranks on one device.
+    share = os.environ.get("VIT_AMD_SHARE_GPU") == "1"
+    ndev = torch.cuda.device_count()
+    local_env = int(os.environ.get("LOCAL_RANK", "0"))
+    if local_env >= ndev and not share:
+        raise SystemExit(f"LOCAL_RANK {local_env} but only {ndev} GPU(s) visible")
+    if share:
+        torch.cuda.set_device(local_env % ndev)
+    rank, world, local = vdist.init_from_env(backend="gloo" if share else None)
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch one process per GPU")
+    local = local % ndev if share else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -131,7 +141,7 @@ def main():
         timer.enabled = False
     if not torch.isfinite(y).all():
         raise SystemExit("non-finite logits")
-    dt = vdist.max_over_ranks(dt, device=dev if world > 1 else "cpu")
+    dt = vdist.max_over_ranks(dt, device=dev if (world > 1 and not share) else "cpu")
 
     if rank == 0:
         F = flops_per_image(cfg, a.img_size)

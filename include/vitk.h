@@ -142,6 +142,15 @@ int vitk_patch_embed_f32(const float* img, const float* w, const float* bias, co
 int vitk_attention_f32(const float* q, const float* k, const float* v, float* ctx, int batch, int heads, int ntok,
                        int hd, float scale, void* stream);
 
+/* ---- next to the forward path --------------------------------------------------------------- */
+
+/* Position-embedding rescale for loading a checkpoint at another resolution:
+ * pos_out[0] = pos_in[0] (cls); the grid_in x grid_in grid of rows pos_in[1:] is resampled to grid_out x
+ * grid_out by order-1 interpolation, output index o at input coordinate o (grid_in-1)/(grid_out-1).
+ * pos_in f32 [1 + grid_in^2, D], pos_out f32 [1 + grid_out^2, D], distinct buffers.
+ * Replaces pos_embed_scale (scipy.ndimage.zoom, order=1, mode='constant') at utils.py:241-261. */
+int vitk_pos_embed_scale(const float* pos_in, float* pos_out, int grid_in, int grid_out, int D, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -190,8 +190,28 @@ def convert_fixture():
     print("convert", len(sd), "keys")
 
 
+def pos_embed_fixture():
+    """The reference's utils.pos_embed_scale (scipy zoom, order 1) on synthetic position embeddings."""
+    import utils as ref_utils                             # reference
+    out = {}
+    cases = [(14, 24, 16, 384), (24, 14, 16, 224), (14, 14, 16, 224), (7, 12, 32, 384), (2, 3, 16, 48)]
+    for i, (g, G, P, S) in enumerate(cases):
+        D = 24
+        pe = torch.from_numpy(np.asarray(synth.normal(11 + i, "pos_embed_scale", (1, 1 + g * g, D), 0.02), dtype=np.float32))
+        want = ref_utils.pos_embed_scale(pe.clone(), img_size=S, patch_size=P)
+        assert want.shape == (1, 1 + G * G, D)
+        out[f"in{i}"], out[f"out{i}"] = np_(pe), np_(want)
+    np.savez(os.path.join(HERE, "pos_embed_scale.npz"), **out)
+    with open(os.path.join(HERE, "pos_embed_scale.json"), "w") as f:
+        json.dump({"cases": [{"grid_in": g, "grid_out": G, "patch_size": P, "img_size": S} for g, G, P, S in cases]}, f)
+    print("pos_embed_scale", len(cases), "cases")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if sys.argv[1:] == ["pos_embed"]:
+        pos_embed_fixture()
+        sys.exit(0)
     keys()
     tiny()
     convert_fixture()

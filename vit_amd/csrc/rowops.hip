@@ -131,4 +131,35 @@ hipError_t launch_cast_f32_bf16(const float* in, void* out, int64_t n, hipStream
     return hipGetLastError();
 }
 
+// Position-embedding rescale (utils.py:241-261): cls row copied, the g x g grid of rows resampled to
+// G x G by order-1 interpolation with output index o at input coordinate o (g-1)/(G-1) per axis (what
+// scipy.ndimage.zoom(order=1) computes).  One block per output row, threads over channels.
+__global__ __launch_bounds__(256) void pos_embed_scale_rows(const float* __restrict__ in, float* __restrict__ out,
+                                                            int g, int G, int D) {
+    const int row = blockIdx.x;                      // output token
+    float w00 = 1.f, w01 = 0.f, w10 = 0.f, w11 = 0.f;
+    int r00 = 0, r01 = 0, r10 = 0, r11 = 0;
+    if (row > 0) {
+        const int oi = (row - 1) / G, oj = (row - 1) - oi * G;
+        const double step = G > 1 ? (double)(g - 1) / (double)(G - 1) : 0.0;
+        const double ci = oi * step, cj = oj * step;
+        int i0 = (int)ci, j0 = (int)cj;
+        i0 = i0 < g - 1 ? i0 : g - 1;
+        j0 = j0 < g - 1 ? j0 : g - 1;
+        const int i1 = i0 + 1 < g ? i0 + 1 : g - 1, j1 = j0 + 1 < g ? j0 + 1 : g - 1;
+        const double fi = ci - i0, fj = cj - j0;
+        w00 = (float)((1.0 - fi) * (1.0 - fj)); w01 = (float)((1.0 - fi) * fj);
+        w10 = (float)(fi * (1.0 - fj));         w11 = (float)(fi * fj);
+        r00 = 1 + i0 * g + j0; r01 = 1 + i0 * g + j1; r10 = 1 + i1 * g + j0; r11 = 1 + i1 * g + j1;
+    }
+    for (int d = threadIdx.x; d < D; d += 256)
+        out[(size_t)row * D + d] = w00 * in[(size_t)r00 * D + d] + w01 * in[(size_t)r01 * D + d] +
+                                   w10 * in[(size_t)r10 * D + d] + w11 * in[(size_t)r11 * D + d];
+}
+
+hipError_t launch_pos_embed_scale(const float* in, float* out, int g, int G, int D, hipStream_t s) {
+    hipLaunchKernelGGL(pos_embed_scale_rows, dim3(1 + G * G), dim3(256), 0, s, in, out, g, G, D);
+    return hipGetLastError();
+}
+
 }  // namespace vitk

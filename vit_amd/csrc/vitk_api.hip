@@ -228,4 +228,12 @@ int vitk_attention_f32(const float* q, const float* k, const float* v, float* ct
                                          reinterpret_cast<hipStream_t>(stream)), "vitk_attention_f32");
 }
 
+int vitk_pos_embed_scale(const float* pos_in, float* pos_out, int grid_in, int grid_out, int D, void* stream) {
+    if (!pos_in || !pos_out) return fail(VITK_ERR_INVALID, "vitk_pos_embed_scale: null pointer");
+    if (grid_in < 1 || grid_out < 1 || D < 1) return fail(VITK_ERR_INVALID, "vitk_pos_embed_scale: non-positive size");
+    if (pos_in == pos_out) return fail(VITK_ERR_INVALID, "vitk_pos_embed_scale: in place is not supported");
+    return launched(launch_pos_embed_scale(pos_in, pos_out, grid_in, grid_out, D, reinterpret_cast<hipStream_t>(stream)),
+                    "vitk_pos_embed_scale");
+}
+
 }  // extern "C"

@@ -26,6 +26,7 @@ from vit_amd import dist as vdist               # noqa: E402
 from vit_amd import ops, synth                  # noqa: E402
 
 MFMA_BF16_PEAK = 2.5166e15     # dense bf16 FLOP/s per MI355X: 256 CU x 2.4 GHz x 4096 FLOP/clk/CU
+FC1_PMC_TRAFFIC = 2 * 182.0e3 * 1024 + 302.6e3 * 1024     # bytes: 2 x FETCH_SIZE KiB + WRITE_SIZE KiB of gemm_bf16_pp<1>
 
 
 def flops_per_image(cfg, img_size, num_classes=1000):
@@ -165,7 +166,10 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_pp<bias+GELU> (fc1)",
                          "achieved": round(achieved, 1), "peak": round(MFMA_BF16_PEAK / 1e12, 1),
                          "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_BF16_PEAK, 4),
-                         "avg_launch_ms": round(k_ms, 4), "launches": len(timer.pairs), "traffic": None},
+                         "avg_launch_ms": round(k_ms, 4), "launches": len(timer.pairs),
+                         # HBM-side bytes of one fc1 launch at the BASELINE shape from rocprofv3 PMC passes
+                         # (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, profiles/r01/pmc_summary.txt); not collected live
+                         "traffic": FC1_PMC_TRAFFIC if (a.arch, a.img_size, a.batch) == ("b16", 224, 256) else None},
         }
         if a.precision != "bf16":
             out.pop("roofline")          # the roofline entry describes the bf16 fc1 kernel only

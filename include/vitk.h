@@ -104,8 +104,9 @@ int vitk_qkv_proj(const void* A, const void* W, const float* bias, void* qkv, in
                   int hd, void* stream);
 
 /* ctx[b, t, h*hd + e] = sum_s softmax_s(q[b,h,t,:] . k[b,h,s,:] * scale) * v[b,h,s,e]
- * q, k, v: bf16 [batch, heads, ntok, hd]; ctx: bf16 [batch, ntok, heads*hd].  hd == 64 or 96 (K and V stream
- * through LDS in 64-key chunks, ntok <= 16384); other head sizes return VITK_ERR_UNSUPPORTED.
+ * q, k, v: bf16 [batch, heads, ntok, hd]; ctx: bf16 [batch, ntok, heads*hd].  hd in {64, 80, 96}, ntok <= 16384
+ * (K and V of a head stay resident in LDS when they fit, else they stream through it in 64-key chunks);
+ * other head sizes return VITK_ERR_UNSUPPORTED.
  * Replaces q@k^T, scaling, softmax, @v, transpose, reshape at models/transformer.py:43-46. */
 int vitk_attention(const void* q, const void* k, const void* v, void* ctx, int batch, int heads, int ntok,
                    int hd, float scale, void* stream);

@@ -35,8 +35,8 @@ def test_argument_errors_are_reported_not_launched():
     p = ctypes.addressof(buf)
     p = (p + 15) & ~15
     assert L.vitk_layernorm(p, 700, p, p, p, 700, 4, 700, 1e-6, 1, None) == 2      # D not supported
-    assert L.vitk_attention(p, p, p, p, 1, 1, 197, 80, 0.1, None) == 2             # head_dim 80
-    assert b"hd=80" in L.vitk_last_error()
+    assert L.vitk_attention(p, p, p, p, 1, 1, 197, 48, 0.1, None) == 2             # head_dim 48
+    assert b"hd=48" in L.vitk_last_error()
     assert L.vitk_attention(p, p, p, p, 1, 1, 20000, 64, 0.1, None) == 2           # too many tokens
     assert L.vitk_gemm_bias_gelu(p, p, p, p, 16, 16, 40, None) == 2                # K % 32
     assert L.vitk_gemm_bias(p, p, p, p, 16, 16, 64, 7, None) == 2                  # dtype code

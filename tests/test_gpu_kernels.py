@@ -174,7 +174,12 @@ def test_attention_long_sequences_stream_through_lds(N, hd):
     _attention_case(1, 2, N, hd, 0)
 
 
-@pytest.mark.parametrize("N,hd", [(197, 96), (577, 64), (33, 64)])
+@pytest.mark.parametrize("B,H,N", [(2, 16, 257), (3, 2, 1), (2, 3, 33), (1, 2, 288), (1, 2, 320)])
+def test_attention_head_dim_80(B, H, N):
+    _attention_case(B, H, N, 80, 0)
+
+
+@pytest.mark.parametrize("N,hd", [(197, 96), (577, 64), (33, 64), (257, 80)])
 def test_attention_forced_streaming(N, hd):
     _attention_case(2, 3, N, hd, 2)
 
@@ -228,7 +233,7 @@ def test_attention_custom_scale_and_row_independence():
 
 
 def test_unsupported_head_dim_raises():
-    qkv = torch.zeros(3, 1, 8, 197, 80, dtype=torch.bfloat16, device=DEV)
-    ctx = torch.empty(1, 197, 640, dtype=torch.bfloat16, device=DEV)
-    with pytest.raises(lib.VitkError, match="hd=80"):
+    qkv = torch.zeros(3, 1, 8, 197, 48, dtype=torch.bfloat16, device=DEV)
+    ctx = torch.empty(1, 197, 384, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(lib.VitkError, match="hd=48"):
         ops.attention(qkv, ctx, 0.1)

@@ -92,10 +92,10 @@ def test_weight_update_invalidates_cache_and_extra_shapes():
 
 
 def test_unsupported_head_dim_is_rejected_not_faked():
-    """head_dim 80 (ViT-H/14) is not covered by the attention kernel: the call must raise rather than
-    fall back to any other implementation."""
+    """A head_dim the attention kernel does not cover: the call must raise rather than fall back to any
+    other implementation."""
     from vit_amd import ops
-    qkv = torch.zeros(3, 1, 2, 197, 80, dtype=torch.bfloat16, device=DEV)
-    ctx = torch.empty(1, 197, 160, dtype=torch.bfloat16, device=DEV)
-    with pytest.raises(vit_amd.VitkError, match="hd=80"):
-        ops.attention(qkv, ctx, 80 ** -0.5)
+    qkv = torch.zeros(3, 1, 2, 197, 48, dtype=torch.bfloat16, device=DEV)
+    ctx = torch.empty(1, 197, 96, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(vit_amd.VitkError, match="hd=48"):
+        ops.attention(qkv, ctx, 48 ** -0.5)

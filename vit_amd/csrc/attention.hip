@@ -1,5 +1,5 @@
 // Flash-style multi-head self-attention forward for ViT token counts
-// (197 / 577 tokens, head_dim 64 or 96) on gfx950 / CDNA4.
+// (197 / 257 / 577 tokens, head_dim 64, 80 or 96) on gfx950 / CDNA4.
 //
 // Reference semantics (models/transformer.py:42-46): per (image, head),
 //   P = softmax(q k^T * scaling) over keys, no mask;  ctx = P v,
@@ -7,7 +7,7 @@
 //
 // One workgroup = one (image, head) and NW q-tiles of 32 rows, one wave per
 // q-tile.  The head's whole K and V ([ntok, head_dim] bf16 each) are staged once
-// in LDS (rows of 128 B at head_dim 64, of 256 B with 64 B unused at head_dim 96);
+// in LDS (rows of 128 B at head_dim 64, of 256 B with the tail unused at head_dim 80 and 96);
 // every wave then walks the keys in blocks of 32 with a wave-private online softmax:
 //   S^T[key][q] = K_blk Q^T    (mfma 32x32x16, key on the MFMA row, q on the lane)
 //   running max / sum per q live in that lane's registers (both half-waves hold
@@ -32,9 +32,9 @@ static int g_attn_probe = 0;   // timing probe (debug variant bit 2): all workgr
 
 // VTR = true : V row-major in LDS, transposed fragments via ds_read_b64_tr_b16.
 // VTR = false: V stored transposed ([d][key]) in LDS, fragments via ds_read_b64.
-// HD = 64 or 96 (VTR only).  LDS slot of 16-byte chunk c of row r:
+// HD = 64, or 80 / 96 (VTR only).  LDS slot of 16-byte chunk c of row r:
 //   HD 64: K c ^ ((r >> 1) & 7), V c ^ (((r >> 1) & 1) << 2) in 128-byte rows;
-//   HD 96: K c ^ (r & 15),       V c ^ ((r & 3) << 2)        in 256-byte rows (12 of 16 slots used),
+//   HD 80, 96: K c ^ (r & 15),   V c ^ ((r & 3) << 2)        in 256-byte rows (10 or 12 of 16 slots used),
 // which makes the ds_read_b128 of 32 rows x one chunk column (K) and the transposed read of 4 rows x 64 B
 // (V) conflict-free in both geometries.
 //
@@ -49,10 +49,11 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
                                                          const bf16_t* __restrict__ V,
                                                          bf16_t* __restrict__ O, int ntok, int heads,
                                                          float scale_log2e, int probe) {
-    static_assert(HD == 64 || (HD == 96 && VTR), "head_dim 64, or 96 with transposed LDS reads");
+    static_assert(HD == 64 || ((HD == 96 || HD == 80) && VTR), "head_dim 64, or 80 / 96 with transposed LDS reads");
     static_assert(VTR || !STREAM, "streaming needs the transposed LDS reads");
     constexpr int KS = HD / 16;                  // k-steps of q k^T
-    constexpr int DB = HD / 32;                  // 32-row blocks of O^T
+    constexpr int DB = (HD + 31) / 32;           // 32-row blocks of O^T (the last one half used at head_dim 80:
+                                                 // its upper V columns are copies of chunk 9, never stored)
     constexpr int RB = HD == 64 ? 128 : 256;     // bytes per K/V row in LDS
     constexpr int RPP = 1024 / RB;               // rows per LDS-DMA piece (one wave instruction = 1 KiB)
     constexpr int CPR = RB / 16;                 // 16-byte slots per LDS row
@@ -260,6 +261,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
             for (int d = 0; d < DB; ++d)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
+                    if (d * 32 + 8 * g >= HD) continue;          // head_dim 80: columns 80..95 do not exist
                     u32x2 pk = {pack_bf16(o_acc[d][4 * g] * inv, o_acc[d][4 * g + 1] * inv),
                                 pack_bf16(o_acc[d][4 * g + 2] * inv, o_acc[d][4 * g + 3] * inv)};
                     *reinterpret_cast<u32x2*>(og + d * 32 + 8 * g) = pk;
@@ -328,16 +330,16 @@ static hipError_t attn_launch(const void* q, const void* k, const void* v, void*
 
 // token counts the kernels take: any with the streamed K/V; the resident variants need K and V of one
 // head in the 160 KiB of LDS (608 tokens at head_dim 64, 288 at head_dim 96)
-int attention_max_tokens(int hd) { return (hd == 64 || hd == 96) ? 16384 : 0; }
+int attention_max_tokens(int hd) { return (hd == 64 || hd == 80 || hd == 96) ? 16384 : 0; }
 
 hipError_t launch_attention(const void* q, const void* k, const void* v, void* out, int batch, int heads,
                             int ntok, int hd, float scale, int variant, hipStream_t s) {
-    if ((hd != 64 && hd != 96) || ntok < 1) return hipErrorInvalidValue;
+    if ((hd != 64 && hd != 80 && hd != 96) || ntok < 1) return hipErrorInvalidValue;
     const int qtiles = (ntok + 31) / 32;
     // variant: 0 = automatic (K/V resident in LDS with transposed reads when they fit, else streamed in
     // 64-key chunks); 1 = resident, V stored transposed (head_dim 64); 2 = streamed
     int mode = variant & 3;
-    const bool fits = ntok <= (hd == 64 ? 608 : 288);
+    const bool fits = ntok <= (hd == 64 ? 608 : 288);      // 128-byte rows at head_dim 64, 256-byte rows else
     if (mode == 3 || (mode == 1 && (hd != 64 || !fits))) return hipErrorInvalidValue;
     if (mode == 0 && !fits) mode = 2;
     g_attn_probe = (variant >> 2) & 3;
@@ -365,6 +367,8 @@ hipError_t launch_attention(const void* q, const void* k, const void* v, void* o
     case NWV:                                                                                                 \
         if (hd == 96 && mode == 2) return attn_launch<96, NWV, true, true>(q, k, v, out, batch, heads, ntok, scale, s);  \
         if (hd == 96) return attn_launch<96, NWV, true, false>(q, k, v, out, batch, heads, ntok, scale, s);   \
+        if (hd == 80 && mode == 2) return attn_launch<80, NWV, true, true>(q, k, v, out, batch, heads, ntok, scale, s);  \
+        if (hd == 80) return attn_launch<80, NWV, true, false>(q, k, v, out, batch, heads, ntok, scale, s);   \
         if (mode == 2) return attn_launch<64, NWV, true, true>(q, k, v, out, batch, heads, ntok, scale, s);   \
         if (mode == 0) return attn_launch<64, NWV, true, false>(q, k, v, out, batch, heads, ntok, scale, s);  \
         return attn_launch<64, NWV, false, false>(q, k, v, out, batch, heads, ntok, scale, s);
@@ -376,6 +380,7 @@ hipError_t launch_attention(const void* q, const void* k, const void* v, void* o
         VITK_ATTN_CASE(8)
         case 10:      // resident modes only
             if (hd == 96) return attn_launch<96, 10, true, false>(q, k, v, out, batch, heads, ntok, scale, s);
+            if (hd == 80) return attn_launch<80, 10, true, false>(q, k, v, out, batch, heads, ntok, scale, s);
             if (mode == 0) return attn_launch<64, 10, true, false>(q, k, v, out, batch, heads, ntok, scale, s);
             return attn_launch<64, 10, false, false>(q, k, v, out, batch, heads, ntok, scale, s);
     }

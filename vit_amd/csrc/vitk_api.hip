@@ -171,7 +171,8 @@ int vitk_attention(const void* q, const void* k, const void* v, void* ctx, int b
     if (batch <= 0 || heads <= 0 || ntok <= 0) return fail(VITK_ERR_INVALID, "vitk_attention: non-positive size");
     if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(ctx))
         return fail(VITK_ERR_INVALID, "vitk_attention: pointers must be 16-byte aligned");
-    if (hd != 64 && hd != 96) return fail(VITK_ERR_UNSUPPORTED, "vitk_attention: hd=%d (64 and 96 are implemented)", hd);
+    if (hd != 64 && hd != 80 && hd != 96)
+        return fail(VITK_ERR_UNSUPPORTED, "vitk_attention: hd=%d (64, 80 and 96 are implemented)", hd);
     if (ntok > attention_max_tokens(hd))
         return fail(VITK_ERR_UNSUPPORTED, "vitk_attention: ntok=%d exceeds the limit %d at hd=%d", ntok,
                     attention_max_tokens(hd), hd);

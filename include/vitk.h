@@ -78,6 +78,15 @@ int vitk_cast_f32_bf16(const float* in, void* out, int64_t n, void* stream);
 int vitk_patch_embed(const void* img, const void* w, const float* bias, const float* cls, const float* pos,
                      float* x, int batch, int img_h, int img_w, int patch, int D, void* stream);
 
+/* The same result for any patch size (ViT-H/14's 14 included), through an explicit patch matrix:
+ * cols: caller-provided scratch, bf16 [batch * (img_h/patch) * (img_w/patch), Kpad] with
+ * Kpad = 3*patch*patch rounded up to a multiple of 64; w_padded: bf16 [D, Kpad], the flattened Conv2d
+ * weight zero-padded to Kpad columns.  At least 128 patch rows, D % 256 == 0.
+ * models/vision_transformer.py:47-50. */
+int vitk_patch_embed_cols(const void* img, const void* w_padded, const float* bias, const float* cls,
+                          const float* pos, float* x, void* cols, int batch, int img_h, int img_w, int patch, int D,
+                          void* stream);
+
 /* out[M,N] = A[M,K] @ W[N,K]^T + bias, A and W bf16, fp32 accumulate; out bf16 or f32 (out_dtype).
  * bias may be NULL.  K % 32 == 0.  Replaces nn.Linear (models/vision_transformer.py:30,55). */
 int vitk_gemm_bias(const void* A, const void* W, const float* bias, void* out, int M, int N, int K,

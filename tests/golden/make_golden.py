@@ -212,6 +212,9 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["pos_embed"]:
         pos_embed_fixture()
         sys.exit(0)
+    if sys.argv[1:] == ["h14"]:
+        full("h14_224_ref", "h14", 224, 2, "reference", pool=8)
+        sys.exit(0)
     keys()
     tiny()
     convert_fixture()

@@ -149,6 +149,27 @@ def test_patch_embed(B, S, P, D, variant):
 
 
 # ----------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("B,S,P,D", [(2, 224, 14, 1280), (3, 224, 16, 768), (2, 126, 14, 256), (1, 230, 12, 512)])
+def test_patch_embed_through_explicit_patch_matrix(B, S, P, D):
+    """Any patch size: im2col into a caller scratch + the tiled GEMM with the patch epilogue."""
+    img = to16(rnd(B, 3, S, S, seed=31))
+    w = to16(rnd(D, 3, P, P, seed=32, scale=0.03))
+    bias, cls = rnd(D, seed=33, scale=0.1), rnd(D, seed=34)
+    n = (S // P) ** 2
+    pos = rnd(n + 1, D, seed=35, scale=0.1)
+    conv = F.conv2d(img.float(), w.float(), bias, stride=P).flatten(2).transpose(1, 2)
+    want = torch.cat([cls.expand(B, 1, D), conv], dim=1) + pos
+    k0 = 3 * P * P
+    kpad = (k0 + 63) // 64 * 64
+    wp = torch.zeros(D, kpad, dtype=torch.bfloat16)
+    wp[:, :k0] = w.reshape(D, -1)
+    out = torch.full((B, n + 1, D), float("nan"), device=DEV)
+    cols = torch.full((B * n, kpad), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.patch_embed_cols(img.to(DEV), wp.to(DEV), bias.to(DEV), cls.to(DEV), pos.to(DEV), out, cols, P)
+    assert torch.allclose(out.cpu(), want, rtol=1e-4, atol=2e-4)
+    assert (cols.float().cpu()[:, k0:] == 0).all()
+
+
 def _attn_ref(q, k, v, scale):
     s = (q.double() @ k.double().transpose(-2, -1)) * scale
     p = s.softmax(-1)

@@ -234,7 +234,7 @@ static hipError_t launch_variant(const GemmArgs& a, int variant, hipStream_t s) 
              (EPI == EPI_PATCH_F32 && (size_t)a.batch * a.ntok * a.N * 4 >= (1ull << 32)))
         // the persistent kernels address operands and outputs with 32-bit byte offsets
         hipLaunchKernelGGL((gemm_bf16_256x256<EPI, GATHER, 0>), dim3(tiles), dim3(kGemmThreads), 0, s, a);
-    else if (variant != 5 && gemm_pp_supports(a, GATHER))
+    else if (variant != 5 && EPI != EPI_PATCH_F32 && gemm_pp_supports(a, GATHER))
         return launch_gemm_pp(a, EPI, s);
     else
         return launch_gemm_pipe(a, EPI, GATHER, s);
@@ -253,6 +253,7 @@ hipError_t launch_gemm_tiled(const GemmArgs& a, int epilogue, bool gather, int v
         case EPI_QKV_BF16: return launch_variant<EPI_QKV_BF16, false>(a, variant, s);
         case EPI_BIAS_F32: return launch_variant<EPI_BIAS_F32, false>(a, variant, s);
         case EPI_BIAS_TANH_BF16: return launch_variant<EPI_BIAS_TANH_BF16, false>(a, variant, s);
+        case EPI_PATCH_F32: return launch_variant<EPI_PATCH_F32, false>(a, variant, s);
         default: return hipErrorInvalidValue;
     }
 }

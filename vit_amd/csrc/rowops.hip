@@ -157,6 +157,41 @@ __global__ __launch_bounds__(256) void pos_embed_scale_rows(const float* __restr
                                    w10 * in[(size_t)r10 * D + d] + w11 * in[(size_t)r11 * D + d];
 }
 
+// Patch rows for patch sizes the gather loader of the GEMM cannot address (not a power of two, e.g.
+// ViT-H/14): cols[m][k] = img[b][c][ph*P + i][pw*P + j] for m = (b, ph, pw), k = c*P*P + i*P + j
+// (the Conv2d weight's flattening, models/vision_transformer.py:18), zero for k in [3*P*P, kpad).
+// One thread per (row m, channel c, patch row i): P contiguous source elements.
+__global__ __launch_bounds__(256) void im2col_patches(const bf16_t* __restrict__ img, bf16_t* __restrict__ cols,
+                                                      int batch, int img_h, int img_w, int patch, int grid_w,
+                                                      int npatch, int kpad) {
+    const int64_t total = (int64_t)batch * npatch * 3 * patch;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int k0 = 3 * patch * patch;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const int i = (int)(t % patch);
+        const int c = (int)((t / patch) % 3);
+        const int64_t m = t / (3 * patch);
+        const int b = (int)(m / npatch), pidx = (int)(m - (int64_t)b * npatch);
+        const int ph = pidx / grid_w, pw = pidx - ph * grid_w;
+        const bf16_t* src = img + (((int64_t)b * 3 + c) * img_h + (ph * patch + i)) * img_w + pw * patch;
+        bf16_t* dst = cols + m * kpad + (c * patch + i) * patch;
+        for (int j = 0; j < patch; ++j) dst[j] = src[j];
+        if (c == 2 && i == patch - 1)
+            for (int k = k0; k < kpad; ++k) cols[m * kpad + k] = (bf16_t)0.0f;
+    }
+}
+
+hipError_t launch_im2col(const void* img, void* cols, int batch, int img_h, int img_w, int patch, int kpad,
+                         hipStream_t s) {
+    const int grid_w = img_w / patch, npatch = (img_h / patch) * grid_w;
+    const int64_t total = (int64_t)batch * npatch * 3 * patch;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(im2col_patches, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(img),
+                       reinterpret_cast<bf16_t*>(cols), batch, img_h, img_w, patch, grid_w, npatch, kpad);
+    return hipGetLastError();
+}
+
 hipError_t launch_pos_embed_scale(const float* in, float* out, int g, int G, int D, hipStream_t s) {
     hipLaunchKernelGGL(pos_embed_scale_rows, dim3(1 + G * G), dim3(256), 0, s, in, out, g, G, D);
     return hipGetLastError();

@@ -120,6 +120,36 @@ int vitk_patch_embed(const void* img, const void* w, const float* bias, const fl
     return launched(launch_gemm_tiled(a, EPI_PATCH_F32, true, v == 2 ? 0 : v, s), "vitk_patch_embed");
 }
 
+int vitk_patch_embed_cols(const void* img, const void* w_padded, const float* bias, const float* cls,
+                          const float* pos, float* x, void* cols, int batch, int img_h, int img_w, int patch, int D,
+                          void* stream) {
+    if (!img || !w_padded || !bias || !cls || !pos || !x || !cols)
+        return fail(VITK_ERR_INVALID, "vitk_patch_embed_cols: null pointer");
+    if (batch <= 0 || img_h <= 0 || img_w <= 0 || patch <= 0 || D <= 0)
+        return fail(VITK_ERR_INVALID, "vitk_patch_embed_cols: non-positive size");
+    if (!aligned16(w_padded) || !aligned16(bias) || !aligned16(cls) || !aligned16(pos) || !aligned16(x) || !aligned16(cols))
+        return fail(VITK_ERR_INVALID, "vitk_patch_embed_cols: pointers must be 16-byte aligned");
+    if (D % 256 != 0) return fail(VITK_ERR_UNSUPPORTED, "vitk_patch_embed_cols: D=%d not a multiple of 256", D);
+    const int gh = img_h / patch, gw = img_w / patch;   // Conv2d without padding floors
+    if (gh < 1 || gw < 1) return fail(VITK_ERR_INVALID, "vitk_patch_embed_cols: image smaller than one patch");
+    const int kpad = (3 * patch * patch + 63) / 64 * 64;
+    if ((size_t)batch * gh * gw < 128)
+        return fail(VITK_ERR_UNSUPPORTED, "vitk_patch_embed_cols: fewer than 128 patch rows");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int rc = launched(launch_im2col(img, cols, batch, img_h, img_w, patch, kpad, s), "vitk_patch_embed_cols(im2col)");
+    if (rc) return rc;
+    GemmArgs a = {};
+    a.A = cols; a.W = w_padded; a.bias = bias; a.out = x; a.pos = pos;
+    a.npatch = gh * gw; a.ntok = a.npatch + 1; a.grid_w = gw;
+    a.M = batch * a.npatch; a.N = D; a.K = kpad;
+    a.lda = kpad; a.ldo = D; a.batch = batch;
+    rc = launched(launch_cls_pos(cls, pos, x, batch, a.ntok, D, s), "vitk_patch_embed_cols(cls)");
+    if (rc) return rc;
+    a.order = g_gemm_variant >> 4;
+    const int v = g_gemm_variant & 15;
+    return launched(launch_gemm_tiled(a, EPI_PATCH_F32, false, v == 2 ? 0 : v, s), "vitk_patch_embed_cols");
+}
+
 int vitk_gemm_bias(const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                    int out_dtype, void* stream) {
     if (out_dtype != VITK_F32 && out_dtype != VITK_BF16)

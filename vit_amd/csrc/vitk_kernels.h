@@ -40,6 +40,8 @@ hipError_t launch_layernorm(const float* x, int64_t x_row_stride, const float* g
                             hipStream_t s);
 hipError_t launch_cls_pos(const float* cls, const float* pos, float* x, int batch, int ntok, int D,
                           hipStream_t s);
+hipError_t launch_im2col(const void* img, void* cols, int batch, int img_h, int img_w, int patch, int kpad,
+                         hipStream_t s);
 hipError_t launch_pos_embed_scale(const float* in, float* out, int g, int G, int D, hipStream_t s);
 hipError_t launch_cast_f32_bf16(const float* in, void* out, int64_t n, hipStream_t s);
 int attention_max_tokens(int hd);

@@ -26,6 +26,11 @@ def _bf16(t):
     return t.detach().to(torch.bfloat16).contiguous()
 
 
+def gather_patch_ok(patch):
+    """Patch sizes the GEMM's im2col-free gather loader addresses: powers of two >= 8."""
+    return patch >= 8 and (patch & (patch - 1)) == 0
+
+
 class WeightCache:
     """Kernel-ready weights.  `fp32=True` (the fp32 compute mode) keeps the GEMM weights in f32: they are
     then the parameters themselves, not copies."""
@@ -52,6 +57,13 @@ class WeightCache:
         D = m.hidden_size
         _bf16 = _f32 if self._fp32 else globals()["_bf16"]       # GEMM weight dtype of this mode
         t["embed.w"] = _bf16(m.embedding.weight).reshape(D, -1)          # OIHW flattened: k = c*P*P + i*P + j
+        if not self._fp32 and not gather_patch_ok(m.patches):
+            # explicit patch matrix: weight columns zero-padded to a multiple of 64
+            k0 = t["embed.w"].shape[1]
+            kpad = (k0 + 63) // 64 * 64
+            wp = torch.zeros(D, kpad, dtype=torch.bfloat16, device=t["embed.w"].device)
+            wp[:, :k0] = t["embed.w"]
+            t["embed.w"] = wp
         t["embed.b"] = _f32(m.embedding.bias)
         t["cls"] = _f32(m.cls_token).reshape(D)
         t["pos"] = _f32(m.pos_embed).reshape(-1, D)
@@ -91,6 +103,12 @@ class Workspace:
         self.pre = e(B, D, dtype=bf)
         self.logits = e(B, ncls, dtype=f32)
         self.img16 = None
+        self.cols = None
+
+    def patch_cols(self, rows, kpad, device):
+        if self.cols is None or tuple(self.cols.shape) != (rows, kpad):
+            self.cols = torch.empty(rows, kpad, dtype=torch.bfloat16, device=device)
+        return self.cols
 
     def image_buffer(self, like):
         if self.img16 is None or self.img16.shape != like.shape:

@@ -22,6 +22,7 @@ SIGNATURES = {
     "vitk_layernorm": [_p, _i64, _p, _p, _p, _i64, _i, _i, _f, _i, _p],
     "vitk_cast_f32_bf16": [_p, _p, _i64, _p],
     "vitk_patch_embed": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "vitk_patch_embed_cols": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "vitk_gemm_bias": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "vitk_gemm_bias_gelu": [_p, _p, _p, _p, _i, _i, _i, _p],
     "vitk_gemm_bias_tanh": [_p, _p, _p, _p, _i, _i, _i, _p],

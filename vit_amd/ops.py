@@ -103,6 +103,29 @@ def patch_embed(img, w, bias, cls, pos, out, patch):
     return out
 
 
+def patch_embed_cols(img, w_padded, bias, cls, pos, out, cols, patch):
+    """Any patch size: img bf16 [B,3,H,W]; w_padded bf16 [D,Kpad] (Kpad = 3*P*P rounded up to 64, zero
+    padded); cols bf16 [B*npatch, Kpad] scratch; out f32 [B,ntok,D]."""
+    L = _lib.load()
+    _chk(img, torch.bfloat16, "img"); _chk(w_padded, torch.bfloat16, "w_padded"); _chk(cols, torch.bfloat16, "cols")
+    for n, t in (("bias", bias), ("cls", cls), ("pos", pos), ("out", out)):
+        _chk(t, torch.float32, n)
+    B, C, H, W = img.shape
+    D = w_padded.shape[0]
+    kpad = (3 * patch * patch + 63) // 64 * 64
+    npatch = (H // patch) * (W // patch)
+    if C != 3 or w_padded.shape[1] != kpad or tuple(cols.shape) != (B * npatch, kpad):
+        raise _lib.VitkError(f"patch_embed_cols: weight {tuple(w_padded.shape)} / cols {tuple(cols.shape)} do not "
+                             f"match [{D},{kpad}] / [{B * npatch},{kpad}]")
+    if tuple(out.shape) != (B, npatch + 1, D) or pos.numel() != (npatch + 1) * D:
+        raise _lib.VitkError(f"patch_embed_cols: out {tuple(out.shape)} / pos {tuple(pos.shape)} do not match "
+                             f"[{B},{npatch + 1},{D}]")
+    with _span("patch_embed"):
+        _lib.check(L.vitk_patch_embed_cols(_ptr(img), _ptr(w_padded), _ptr(bias), _ptr(cls), _ptr(pos), _ptr(out),
+                                           _ptr(cols), B, H, W, patch, D, _stream()), L)
+    return out
+
+
 def _dense_shapes(a, w, out, name):
     M, K = a.shape
     N = w.shape[0]

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .engine import WeightCache, Workspace
+from .engine import WeightCache, Workspace, gather_patch_ok
 from .lib import EPI_TANH, VitkError
 from .transformer import Encoder
 
@@ -125,7 +125,11 @@ class VisionTransformer(nn.Module):
         else:
             raise VitkError(f"unsupported image dtype {x.dtype}")
 
-        ops.patch_embed(img16, w["embed.w"], w["embed.b"], w["cls"], w["pos"], ws.x, P)
+        if gather_patch_ok(P):
+            ops.patch_embed(img16, w["embed.w"], w["embed.b"], w["cls"], w["pos"], ws.x, P)
+        else:
+            cols = ws.patch_cols(B * (N - 1), w["embed.w"].shape[1], x.device)
+            ops.patch_embed_cols(img16, w["embed.w"], w["embed.b"], w["cls"], w["pos"], ws.x, cols, P)
         feat = self.encoder.fused(ws, w)
         if "pre.w" in w:
             ops.gemm_bias_tanh(feat, w["pre.w"], w["pre.b"], ws.pre)

@@ -161,6 +161,19 @@ int vitk_attention_f32(const float* q, const float* k, const float* v, float* ct
  * Replaces pos_embed_scale (scipy.ndimage.zoom, order=1, mode='constant') at utils.py:241-261. */
 int vitk_pos_embed_scale(const float* pos_in, float* pos_out, int grid_in, int grid_out, int D, void* stream);
 
+/* Input step in front of the forward: out[b,c,y,x] = (float(img[b,c,y,x]) - mean[c]) / std[c].
+ * img: uint8 [batch,3,img_h,img_w] (what fast_collate builds, data.py:143-154); mean, std: HOST pointers to 3
+ * floats in pixel units (the reference's 0.485*255 ... / 0.229*255 ..., data.py:54-55); out bf16 or f32
+ * (out_dtype), img_h*img_w % 16 == 0.  Replaces .float().sub_(mean).div_(std) at data.py:69-72. */
+int vitk_normalize_u8(const void* img, void* out, int batch, int img_h, int img_w, const float* mean,
+                      const float* std, int out_dtype, void* stream);
+
+/* Step after the forward: rank[r] = number of classes ranked above target[r] in logits[r, :] (ties towards
+ * the lower class index), so the prediction is correct at k iff rank[r] < k; targets outside [0, classes)
+ * get rank = classes.  logits f32 [rows, classes], target int64 [rows], rank int32 [rows].
+ * Replaces topk + eq + sum of accuracy() at utils.py:182-195. */
+int vitk_target_rank(const float* logits, const int64_t* target, int* rank, int rows, int classes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

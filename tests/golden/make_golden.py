@@ -207,8 +207,30 @@ def pos_embed_fixture():
     print("pos_embed_scale", len(cases), "cases")
 
 
+def accuracy_fixture():
+    """The reference's utils.accuracy on synthetic logits whose targets sit at chosen ranks."""
+    import utils as ref_utils                             # reference
+    out = {}
+    cases = [(64, 1000, (1, 5)), (7, 10, (1, 3)), (128, 1000, (1, 5)), (3, 21843, (1, 5, 10))]
+    for i, (B, C, topk) in enumerate(cases):
+        logits = torch.from_numpy(np.asarray(synth.normal(21 + i, "accuracy", (B, C), 1.0), dtype=np.float32))
+        order = logits.argsort(dim=1, descending=True)
+        want_rank = torch.from_numpy(np.random.RandomState(i).randint(0, 2 * max(topk), size=B))
+        target = order.gather(1, want_rank.clamp(max=C - 1).view(-1, 1)).view(-1)
+        res = ref_utils.accuracy(logits, target, topk=topk)
+        out[f"logits{i}"], out[f"target{i}"] = np_(logits), np_(target)
+        out[f"res{i}"] = np.array([float(r) for r in res], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "accuracy.npz"), **out)
+    with open(os.path.join(HERE, "accuracy.json"), "w") as f:
+        json.dump({"cases": [{"batch": B, "classes": C, "topk": list(t)} for B, C, t in cases]}, f)
+    print("accuracy", len(cases), "cases")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if sys.argv[1:] == ["accuracy"]:
+        accuracy_fixture()
+        sys.exit(0)
     if sys.argv[1:] == ["pos_embed"]:
         pos_embed_fixture()
         sys.exit(0)

@@ -86,6 +86,16 @@ def main():
     o16 = torch.empty(R, D, dtype=bf, device=dev)
     rec("gemm_bias bf16 (DxD, no epilogue math)", timeit(lambda: ops.gemm_bias(y, w_out, b_d, o16), it),
         flops=2.0 * R * D * D)
+    npx = B * 3 * a.img_size * a.img_size
+    img8 = torch.randint(0, 256, (B, 3, a.img_size, a.img_size), device=dev, dtype=torch.uint8)
+    mean, std = (123.675, 116.28, 103.53), (58.395, 57.12, 57.375)
+    rec("normalize u8->bf16 (input step)", timeit(lambda: ops.normalize_u8(img8, mean, std, img), it), bytes_=npx * 3)
+    img32 = torch.empty(B, 3, a.img_size, a.img_size, dtype=f32, device=dev)
+    rec("normalize u8->f32", timeit(lambda: ops.normalize_u8(img8, mean, std, img32), it), bytes_=npx * 5)
+    logits = rn(B, 1000, dt=f32)
+    tgt = torch.randint(0, 1000, (B,), device=dev)
+    rk = torch.empty(B, dtype=torch.int32, device=dev)
+    rec("target_rank (accuracy)", timeit(lambda: ops.target_rank(logits, tgt, rk), it), bytes_=B * 1000 * 4)
     L = cfg["num_layers"]
     per_layer = sum(t for n, t in rows if n in ("qkv_proj", "attention", "out_proj + residual",
                                                "fc1 + bias + GELU", "fc2 + residual")) + 2 * rows[0][1]

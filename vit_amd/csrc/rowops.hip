@@ -192,6 +192,85 @@ hipError_t launch_im2col(const void* img, void* cols, int batch, int img_h, int 
     return hipGetLastError();
 }
 
+// Input step in front of the forward (data.py:59-72, DataFetcher.preload): uint8 NCHW pixels ->
+// (float(x) - mean[c]) / std[c], written as bf16 (the patch GEMM's operand type) or f32.  16 pixels per
+// lane per step: one 16-byte load, two 16-byte bf16 stores (or four f32 ones).
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void normalize_u8(const uint8_t* __restrict__ in, void* __restrict__ out,
+                                                    int64_t n16, int64_t plane16, float m0, float m1, float m2,
+                                                    float s0, float s1, float s2) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        const int c = (int)((i / plane16) % 3);               // a 16-pixel group never straddles a channel plane
+        const float m = c == 0 ? m0 : c == 1 ? m1 : m2, sd = c == 0 ? s0 : c == 1 ? s1 : s2;
+        const u32x4 px = *reinterpret_cast<const u32x4*>(in + i * 16);
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = ((float)((px[j >> 2] >> (8 * (j & 3))) & 0xFFu) - m) / sd;
+        if constexpr (OUT_BF16) {
+            bf16_t* o = reinterpret_cast<bf16_t*>(out) + i * 16;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                u32x4 w = {pack_bf16(v[8 * h], v[8 * h + 1]), pack_bf16(v[8 * h + 2], v[8 * h + 3]),
+                           pack_bf16(v[8 * h + 4], v[8 * h + 5]), pack_bf16(v[8 * h + 6], v[8 * h + 7])};
+                *reinterpret_cast<u32x4*>(o + 8 * h) = w;
+            }
+        } else {
+            float* o = reinterpret_cast<float*>(out) + i * 16;
+#pragma unroll
+            for (int h = 0; h < 4; ++h)
+                *reinterpret_cast<f32x4*>(o + 4 * h) = f32x4{v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
+        }
+    }
+}
+
+hipError_t launch_normalize_u8(const void* in, void* out, int64_t n, int64_t plane, const float* mean,
+                               const float* std, bool out_bf16, hipStream_t s) {
+    const int64_t n16 = n / 16;
+    int64_t blocks = (n16 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    if (out_bf16)
+        hipLaunchKernelGGL(normalize_u8<true>, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const uint8_t*>(in),
+                           out, n16, plane / 16, mean[0], mean[1], mean[2], std[0], std[1], std[2]);
+    else
+        hipLaunchKernelGGL(normalize_u8<false>, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const uint8_t*>(in),
+                           out, n16, plane / 16, mean[0], mean[1], mean[2], std[0], std[1], std[2]);
+    return hipGetLastError();
+}
+
+// Step after the forward (utils.py:182-195, accuracy): rank[b] = position of the target class in the
+// descending order of logits[b] (0 = top-1), ties broken towards the lower class index, so
+// "correct at k" is rank < k.  One wave per row.
+__global__ __launch_bounds__(256) void target_rank_rows(const float* __restrict__ logits,
+                                                        const int64_t* __restrict__ target, int* __restrict__ rank,
+                                                        int rows, int classes) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* x = logits + (size_t)row * classes;
+    const int64_t t = target[row];
+    if (t < 0 || t >= classes) {                  // not a class: never counted as correct
+        if (lane == 0) rank[row] = classes;
+        return;
+    }
+    const float xt = x[t];
+    int above = 0;
+    for (int j = lane; j < classes; j += 64) {
+        const float v = x[j];
+        above += (v > xt || (v == xt && j < (int)t)) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) above += __shfl_xor(above, o, 64);
+    if (lane == 0) rank[row] = above;
+}
+
+hipError_t launch_target_rank(const float* logits, const int64_t* target, int* rank, int rows, int classes,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(target_rank_rows, dim3((rows + 3) / 4), dim3(256), 0, s, logits, target, rank, rows, classes);
+    return hipGetLastError();
+}
+
 hipError_t launch_pos_embed_scale(const float* in, float* out, int g, int G, int D, hipStream_t s) {
     hipLaunchKernelGGL(pos_embed_scale_rows, dim3(1 + G * G), dim3(256), 0, s, in, out, g, G, D);
     return hipGetLastError();

@@ -267,4 +267,26 @@ int vitk_pos_embed_scale(const float* pos_in, float* pos_out, int grid_in, int g
                     "vitk_pos_embed_scale");
 }
 
+int vitk_normalize_u8(const void* img, void* out, int batch, int img_h, int img_w, const float* mean,
+                      const float* std, int out_dtype, void* stream) {
+    if (!img || !out || !mean || !std) return fail(VITK_ERR_INVALID, "vitk_normalize_u8: null pointer");
+    if (batch <= 0 || img_h <= 0 || img_w <= 0) return fail(VITK_ERR_INVALID, "vitk_normalize_u8: non-positive size");
+    if (out_dtype != VITK_F32 && out_dtype != VITK_BF16)
+        return fail(VITK_ERR_UNSUPPORTED, "vitk_normalize_u8: out_dtype=%d", out_dtype);
+    if (!aligned16(img) || !aligned16(out)) return fail(VITK_ERR_INVALID, "vitk_normalize_u8: pointers must be 16-byte aligned");
+    const int64_t plane = (int64_t)img_h * img_w;
+    if (plane % 16 != 0) return fail(VITK_ERR_UNSUPPORTED, "vitk_normalize_u8: img_h*img_w=%lld not a multiple of 16", (long long)plane);
+    for (int c = 0; c < 3; ++c)
+        if (!(std[c] > 0.f)) return fail(VITK_ERR_INVALID, "vitk_normalize_u8: std[%d] must be positive", c);
+    return launched(launch_normalize_u8(img, out, (int64_t)batch * 3 * plane, plane, mean, std, out_dtype == VITK_BF16,
+                                        reinterpret_cast<hipStream_t>(stream)), "vitk_normalize_u8");
+}
+
+int vitk_target_rank(const float* logits, const int64_t* target, int* rank, int rows, int classes, void* stream) {
+    if (!logits || !target || !rank) return fail(VITK_ERR_INVALID, "vitk_target_rank: null pointer");
+    if (rows <= 0 || classes <= 0) return fail(VITK_ERR_INVALID, "vitk_target_rank: non-positive size");
+    return launched(launch_target_rank(logits, target, rank, rows, classes, reinterpret_cast<hipStream_t>(stream)),
+                    "vitk_target_rank");
+}
+
 }  // extern "C"

@@ -42,6 +42,10 @@ hipError_t launch_cls_pos(const float* cls, const float* pos, float* x, int batc
                           hipStream_t s);
 hipError_t launch_im2col(const void* img, void* cols, int batch, int img_h, int img_w, int patch, int kpad,
                          hipStream_t s);
+hipError_t launch_normalize_u8(const void* in, void* out, int64_t n, int64_t plane, const float* mean,
+                               const float* std, bool out_bf16, hipStream_t s);
+hipError_t launch_target_rank(const float* logits, const int64_t* target, int* rank, int rows, int classes,
+                              hipStream_t s);
 hipError_t launch_pos_embed_scale(const float* in, float* out, int g, int G, int D, hipStream_t s);
 hipError_t launch_cast_f32_bf16(const float* in, void* out, int64_t n, hipStream_t s);
 int attention_max_tokens(int hd);

@@ -110,7 +110,7 @@ class Workspace:
             self.cols = torch.empty(rows, kpad, dtype=torch.bfloat16, device=device)
         return self.cols
 
-    def image_buffer(self, like):
-        if self.img16 is None or self.img16.shape != like.shape:
-            self.img16 = torch.empty(like.shape, dtype=torch.bfloat16, device=like.device)
+    def image_buffer(self, like, dtype=torch.bfloat16):
+        if self.img16 is None or self.img16.shape != like.shape or self.img16.dtype != dtype:
+            self.img16 = torch.empty(like.shape, dtype=dtype, device=like.device)
         return self.img16

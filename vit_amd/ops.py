@@ -266,3 +266,37 @@ def attention_f32(qkv, ctx, scale):
         _lib.check(L.vitk_attention_f32(_ptr(qkv[0]), _ptr(qkv[1]), _ptr(qkv[2]), _ptr(ctx), B, H, N, hd,
                                         float(scale), _stream()), L)
     return ctx
+
+
+def normalize_u8(img, mean, std, out):
+    """out = (float(img) - mean[c]) / std[c]; img uint8 [B,3,H,W], out bf16 or f32 of the same shape."""
+    L = _lib.load()
+    _chk(img, torch.uint8, "img")
+    _chk(out, out.dtype, "out")
+    if img.dim() != 4 or img.shape[1] != 3 or out.shape != img.shape:
+        raise _lib.VitkError(f"normalize_u8: expected [B,3,H,W] in and out, got {tuple(img.shape)} / {tuple(out.shape)}")
+    if out.dtype not in (torch.bfloat16, torch.float32):
+        raise _lib.VitkError(f"normalize_u8: out must be bf16 or f32, got {out.dtype}")
+    od = _lib.VITK_BF16 if out.dtype == torch.bfloat16 else _lib.VITK_F32
+    m = (_lib.ctypes.c_float * 3)(*[float(v) for v in mean])
+    sd = (_lib.ctypes.c_float * 3)(*[float(v) for v in std])
+    B, _, H, W = img.shape
+    with _span("normalize_u8"):
+        _lib.check(L.vitk_normalize_u8(_ptr(img), _ptr(out), B, H, W, m, sd, od, _stream()), L)
+    return out
+
+
+def target_rank(logits, target, out=None):
+    """rank[r] = number of classes placed above target[r] in logits[r] (int32 [rows])."""
+    L = _lib.load()
+    _chk(logits, torch.float32, "logits")
+    _chk(target, torch.int64, "target")
+    if logits.dim() != 2 or target.dim() != 1 or target.shape[0] != logits.shape[0]:
+        raise _lib.VitkError(f"target_rank: expected [rows,classes] and [rows], got {tuple(logits.shape)} / {tuple(target.shape)}")
+    if out is None:
+        out = torch.empty(logits.shape[0], dtype=torch.int32, device=logits.device)
+    _chk(out, torch.int32, "rank")
+    with _span("target_rank"):
+        _lib.check(L.vitk_target_rank(_ptr(logits), _ptr(target), _ptr(out), logits.shape[0], logits.shape[1],
+                                      _stream()), L)
+    return out

@@ -1,4 +1,4 @@
-"""The one helper of the reference's utils.py that sits next to the forward path.
+"""The helpers of the reference's utils.py / data.py that sit either side of the forward path.
 
 `pos_embed_scale` mirrors /root/reference/utils.py:241-261 (same name, arguments and return convention): it
 lets a checkpoint trained at one resolution load into a model built for another (utils.py:234-235).  The
@@ -9,6 +9,42 @@ import math
 import torch
 
 from . import lib as _lib
+from . import ops as _ops
+
+# The reference's input statistics in uint8 pixel units (data.py:54-55).
+PIXEL_MEAN = (0.485 * 255, 0.456 * 255, 0.406 * 255)
+PIXEL_STD = (0.229 * 255, 0.224 * 255, 0.225 * 255)
+
+
+def normalize_u8(images, mean=PIXEL_MEAN, std=PIXEL_STD, dtype=torch.float32, out=None):
+    """The DataFetcher's on-GPU input step (data.py:69-72): uint8 [B,3,H,W] -> (float(x) - mean) / std.
+
+    dtype=torch.float32 gives exactly what the reference hands to the model; dtype=torch.bfloat16 writes the
+    patch GEMM's operand type directly (the model does this itself when it is called with uint8 images)."""
+    if not images.is_cuda:
+        raise _lib.VitkError("normalize_u8 needs a CUDA/HIP tensor: this path has no CPU fallback")
+    if out is None:
+        out = torch.empty(images.shape, dtype=dtype, device=images.device)
+    with torch.cuda.device(images.device):
+        return _ops.normalize_u8(images.contiguous(), mean, std, out)
+
+
+def accuracy(output, target, topk=(1,)):
+    """Precision@k in percent, one [1]-shaped tensor per k, as utils.py:182-195 returns them.
+
+    One kernel ranks the target class of every row; no top-k index matrix is built.  Ties in the logits
+    count towards the lower class index."""
+    if not output.is_cuda:
+        raise _lib.VitkError("accuracy needs CUDA/HIP tensors: this path has no CPU fallback")
+    batch_size = target.size(0)
+    with torch.cuda.device(output.device):
+        rank = _ops.target_rank(output.detach().float().contiguous(),
+                                target.to(device=output.device, dtype=torch.int64).contiguous())
+    res = []
+    for k in topk:
+        correct_k = (rank < k).float().sum(0, keepdim=True)
+        res.append(correct_k.mul_(100.0 / batch_size))
+    return res
 
 
 def pos_embed_scale(pos_embed, img_size, patch_size, mode='constant', order=1):

@@ -19,6 +19,7 @@ from . import ops
 from .engine import WeightCache, Workspace, gather_patch_ok
 from .lib import EPI_TANH, VitkError
 from .transformer import Encoder
+from .utils import PIXEL_MEAN, PIXEL_STD
 
 
 class VisionTransformer(nn.Module):
@@ -31,6 +32,8 @@ class VisionTransformer(nn.Module):
         # accumulation and residual stream) or "fp32" (every op in f32, as the reference computes with
         # fp32 parameters).  Also settable later with set_precision().
         self.precision = "bf16"
+        # Statistics applied to uint8 images (the reference's loader-side normalisation, data.py:54-55).
+        self.pixel_mean, self.pixel_std = PIXEL_MEAN, PIXEL_STD
         self.set_precision(kwargs.get("precision", "bf16"))
         self.num_classes = num_classes
         self.hidden_size = hidden_size
@@ -108,7 +111,9 @@ class VisionTransformer(nn.Module):
         out_dtype = self.head.weight.dtype
 
         if self.precision == "fp32":
-            if x.dtype not in (torch.float32, torch.bfloat16):
+            if x.dtype == torch.uint8:
+                x = ops.normalize_u8(x.contiguous(), self.pixel_mean, self.pixel_std, ws.image_buffer(x, torch.float32))
+            elif x.dtype not in (torch.float32, torch.bfloat16):
                 raise VitkError(f"unsupported image dtype {x.dtype}")
             ops.patch_embed_f32(x.float().contiguous(), w["embed.w"], w["embed.b"], w["cls"], w["pos"], ws.x, P)
             feat = self.encoder.fused(ws, w)
@@ -122,6 +127,10 @@ class VisionTransformer(nn.Module):
             img16 = x.contiguous()
         elif x.dtype == torch.float32:
             img16 = ops.cast_bf16(x.contiguous(), ws.image_buffer(x))
+        elif x.dtype == torch.uint8:
+            # Raw loader output (data.py:143-154): the DataFetcher's normalisation (data.py:69-72) writes the
+            # patch GEMM's bf16 operand directly, 1 byte read + 2 written per pixel instead of 4 + 4 + 4 + 2.
+            img16 = ops.normalize_u8(x.contiguous(), self.pixel_mean, self.pixel_std, ws.image_buffer(x))
         else:
             raise VitkError(f"unsupported image dtype {x.dtype}")
 

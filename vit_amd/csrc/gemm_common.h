@@ -86,7 +86,8 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
                     const f32x4 a = acc[nt][pass * 2 + m2];
                     float v0 = a[0] + b4[nt][0], v1 = a[1] + b4[nt][1], v2 = a[2] + b4[nt][2], v3 = a[3] + b4[nt][3];
                     if constexpr (EPI == EPI_BIAS_GELU_BF16) {
-                        const f32x2 g01 = gelu_erf_x2(f32x2{v0, v1}), g23 = gelu_erf_x2(f32x2{v2, v3});
+                        f32x2 g01 = {v0, v1}, g23 = {v2, v3};
+                        gelu_erf_x4(g01, g23);
                         v0 = g01[0]; v1 = g01[1]; v2 = g23[0]; v3 = g23[1];
                     }
                     if constexpr (EPI == EPI_BIAS_TANH_BF16) {

@@ -50,10 +50,12 @@ const char* vitk_last_error(void);
  *   Timing probes, which produce WRONG OR NO RESULTS: order bits 17-19 on the bias -> bf16 epilogue of
  *   the default kernel (1 = no DMA, 2 = no epilogue, 3 = accumulator clearing instead of the zero C
  *   operand, 7 = cycle stamps written over out[0..]), order bit 22 = bf16 epilogues without stores.
- * attention_variant, low 2 bits: 0 = automatic (whole K/V of a head resident in LDS with transposed LDS
- *   reads when they fit: ntok <= 608 at head_dim 64, 288 at 96; else streamed), 1 = resident with V stored
- *   transposed (head_dim 64), 2 = K/V streamed through LDS in 64-key chunks; bit 3 = timing probe
- *   without the key loop (wrong results).
+ * attention_variant, low 2 bits: 0 = automatic (persistent workgroups that hold two heads' K/V in LDS and
+ *   stage the next head under the current one's key loop when two heads fit: ntok <= 256 at head_dim 64,
+ *   160 at 80 / 96; one head per workgroup when one fits: ntok <= 608 / 288; else streamed), 1 = one head
+ *   per workgroup with V stored transposed (head_dim 64), 2 = K/V streamed through LDS in 64-key chunks,
+ *   3 = one head per workgroup; timing probes (WRONG OR NO RESULTS): bit 2 = K/V of head 0 for every
+ *   head, bit 3 = no key loop, bit 4 = no output stores.
  * Process-global; apart from the probes, results are identical across variants up to fp32 summation
  * order. */
 void vitk_set_debug_variant(int gemm_variant, int attention_variant);

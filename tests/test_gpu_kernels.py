@@ -178,7 +178,7 @@ def _attn_ref(q, k, v, scale):
     return o.transpose(1, 2).reshape(B, N, H * hd).float()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("B,H,N", [(2, 12, 197), (1, 12, 577), (3, 2, 1), (2, 3, 32), (2, 3, 33), (1, 4, 224),
                                    (1, 2, 225), (2, 16, 197), (1, 1, 608), (2, 2, 64), (2, 2, 65), (1, 2, 129)])
 def test_attention(B, H, N, variant):
@@ -205,8 +205,16 @@ def test_attention_forced_streaming(N, hd):
     _attention_case(2, 3, N, hd, 2)
 
 
+@pytest.mark.parametrize("B,H,N,hd", [(30, 12, 197, 64), (70, 12, 50, 64), (23, 16, 129, 96), (40, 16, 160, 80),
+                                      (25, 12, 320, 64), (20, 16, 256, 64), (30, 12, 225, 64)])
+def test_attention_more_heads_than_workgroups(B, H, N, hd):
+    """More (image, head) pairs than CUs: the persistent workgroups walk several heads each through
+    their two K/V buffers (some one head more than others)."""
+    _attention_case(B, H, N, hd, 0)
+
+
 def _attention_case(B, H, N, hd, variant):
-    if variant == 1 and N > 608:
+    if variant in (1, 3) and N > 608:
         pytest.skip("resident K/V needs ntok <= 608")
     lib.load().vitk_set_debug_variant(0, variant)
     qkv = to16(rnd(3, B, H, N, hd, seed=N + variant))

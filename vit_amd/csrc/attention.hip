@@ -18,6 +18,7 @@
 // The [ntok, ntok] score matrix never exists in memory.
 #include <type_traits>
 
+#include "gemm_plan.h"
 #include "vitk_common.h"
 #include "vitk_kernels.h"
 
@@ -28,7 +29,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
 
 constexpr float kMaskedScore = -1.0e30f;
-static int g_attn_probe = 0;   // timing probe (debug variant bit 2): all workgroups read head 0
+static int g_attn_probe = 0;   // timing probes (debug variant bits 2..4): K/V of head 0, no key loop, no stores
 
 // VTR = true : V row-major in LDS, transposed fragments via ds_read_b64_tr_b16.
 // VTR = false: V stored transposed ([d][key]) in LDS, fragments via ds_read_b64.
@@ -43,14 +44,20 @@ static int g_attn_probe = 0;   // timing probe (debug variant bit 2): all workgr
 // waves work on chunk c, the LDS-DMA of chunk c+1 is in flight; one barrier per chunk.  32 KiB (64 KiB at
 // head_dim 96) of LDS per workgroup whatever the token count, so several workgroups share a CU and the
 // first MFMA waits for 16 KiB instead of the whole head.
-template <int HD, int NW, bool VTR, bool STREAM>
+//
+// PD = true (VTR, not STREAM): persistent workgroups, one per CU, each walking heads blockIdx.x,
+// blockIdx.x + gridDim.x, ... with two K/V buffers: the LDS-DMA of the next head (and the loads of its
+// queries) run under the current head's key loop, so the memory system never waits for a workgroup to
+// retire and the next one to be launched.  Needs two heads' K and V in LDS.
+template <int HD, int NW, bool VTR, bool STREAM, bool PD = false>
 __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restrict__ Q,
                                                          const bf16_t* __restrict__ K,
                                                          const bf16_t* __restrict__ V,
                                                          bf16_t* __restrict__ O, int ntok, int heads,
-                                                         float scale_log2e, int probe) {
+                                                         float scale_log2e, int probe, int nbh) {
     static_assert(HD == 64 || ((HD == 96 || HD == 80) && VTR), "head_dim 64, or 80 / 96 with transposed LDS reads");
     static_assert(VTR || !STREAM, "streaming needs the transposed LDS reads");
+    static_assert(!PD || (VTR && !STREAM), "the persistent variant stages whole heads by LDS-DMA");
     constexpr int KS = HD / 16;                  // k-steps of q k^T
     constexpr int DB = (HD + 31) / 32;           // 32-row blocks of O^T (the last one half used at head_dim 80:
                                                  // its upper V columns are copies of chunk 9, never stored)
@@ -64,7 +71,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int bh = blockIdx.x;                     // image * heads + head
+    int bh = blockIdx.x;                           // image * heads + head
     const int kblocks = (ntok + 31) >> 5;
     const int kpad = kblocks * 32;
     const int vts = kpad + 4;    // V^T row stride in elements (VTR = false)
@@ -74,15 +81,16 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
 
     auto k_swz = [](int row) { return HD == 64 ? ((row >> 1) & 7) : (row & 15); };
     auto v_swz = [](int row) { return HD == 64 ? (((row >> 1) & 1) << 2) : ((row & 3) << 2); };
-    const bf16_t* kg = K + (size_t)bh * ntok * HD;
-    const bf16_t* vg = V + (size_t)bh * ntok * HD;
 
     // LDS-DMA of `pieces` K pieces followed by `pieces` V pieces (RPP rows each) starting at key row
     // `row0`, into `dst`.  One wave instruction moves 1 KiB; LDS is written linearly, so the slot XOR is
     // applied to each lane's SOURCE chunk.  Rows past ntok re-read the last row (finite values: such keys
     // are masked out of the softmax, and their P is 0 in P.V); at head_dim 96 the slots whose chunk would
     // be 12..15 re-read chunk 11 and are never read back.
-    auto stage = [&](char* dst, int row0, int pieces) {
+    auto stage = [&](char* dst, int row0, int pieces, int head) {
+        if (probe & 1) head = 0;                            // timing probe: K/V from one head (cache-resident)
+        const bf16_t* kg = K + (size_t)head * ntok * HD;
+        const bf16_t* vg = V + (size_t)head * ntok * HD;
         for (int pi = wave; pi < 2 * pieces; pi += NW) {     // wave-uniform
             const bool is_v = pi >= pieces;
             const int lrow = (is_v ? pi - pieces : pi) * RPP + lane / CPR;
@@ -96,12 +104,14 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
     };
 
     if constexpr (STREAM) {
-        stage(smem, 0, KC / RPP);
+        stage(smem, 0, KC / RPP, bh);
     } else if constexpr (VTR) {
-        stage(smem, 0, kpad / RPP);
+        stage(smem, 0, kpad / RPP, bh);
     } else if constexpr (HD == 64) {
         char* kw = smem;
         char* vw = smem + kpad * RB;
+        const bf16_t* kg = K + (size_t)bh * ntok * HD;
+        const bf16_t* vg = V + (size_t)bh * ntok * HD;
         for (int cid = tid; cid < kpad * 8; cid += NW * 64) {
             const int row = cid >> 3, c = cid & 7;
             u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
@@ -126,13 +136,13 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
     int q0 = (STREAM ? blockIdx.y * NW + wave : wave) * 32;
     int qrow = q0 + r;
     bf16x8 qf[KS];
-    auto load_q = [&]() {
-        const int qld = qrow < ntok ? qrow : ntok - 1;   // padded rows re-read the last row; never stored
-        const bf16_t* qg = Q + ((size_t)bh * ntok + qld) * HD + hh * 8;
+    auto load_q = [&](bf16x8 (&dst)[KS], int head, int row) {
+        const int qld = row < ntok ? row : ntok - 1;     // padded rows re-read the last row; never stored
+        const bf16_t* qg = Q + ((size_t)head * ntok + qld) * HD + hh * 8;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qg + ks * 16);
+        for (int ks = 0; ks < KS; ++ks) dst[ks] = *reinterpret_cast<const bf16x8*>(qg + ks * 16);
     };
-    load_q();
+    load_q(qf, bh, qrow);
 
     f32x16 o_acc[DB];
     auto clear_o = [&]() {
@@ -254,8 +264,33 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
     auto finish = [&]() {
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = 1.0f / l_tot;
-        if (qrow < ntok) {
-            const int b = bh / heads, h = bh - b * heads;
+        const int b = bh / heads, h = bh - b * heads;
+        if constexpr (PD && HD == 64) {
+            // Through a wave-private 32 x 128 B window, so that every store instruction writes 8 whole rows
+            // of the head's 128-byte output slice instead of 8 bytes of 64 different rows.  8-byte piece
+            // (row q, chunk c, half hh) lives at 128 q + 16 (c ^ (q & 7)) + 8 (hh ^ ((q >> 3) & 1)):
+            // conflict-free for these writes (16 rows, one column) and for the row-wise 16-byte reads.
+            char* win = smem + 4 * kpad * RB + wave * 4096;
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2 pk = {pack_bf16(o_acc[d][4 * g] * inv, o_acc[d][4 * g + 1] * inv),
+                                pack_bf16(o_acc[d][4 * g + 2] * inv, o_acc[d][4 * g + 3] * inv)};
+                    *reinterpret_cast<u32x2*>(win + r * 128 + (((d * 4 + g) ^ (r & 7)) << 4) + ((hh ^ ((r >> 3) & 1)) << 3)) = pk;
+                }
+            const int rc = lane >> 3, cc = lane & 7;
+            if (!(probe & 4)) {                                  // probe bit 2: no output stores (timing only)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = i * 8 + rc;
+                    u32x4 v = *reinterpret_cast<const u32x4*>(win + row * 128 + ((cc ^ (row & 7)) << 4));
+                    if (i & 1) v = u32x4{v[2], v[3], v[0], v[1]};  // rows 8..15 and 24..31 hold swapped halves
+                    if (q0 + row < ntok)
+                        *reinterpret_cast<u32x4*>(O + (((size_t)b * ntok + q0 + row) * heads + h) * HD + cc * 8) = v;
+                }
+            }
+        } else if (qrow < ntok && !(probe & 4)) {
             bf16_t* og = O + (((size_t)b * ntok + qrow) * heads + h) * HD + 4 * hh;
 #pragma unroll
             for (int d = 0; d < DB; ++d)
@@ -277,7 +312,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
             // every wave is done reading chunk c-1, whose buffer chunk c+1 now overwrites
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (c + 1 < nchunks) stage(smem + ((c + 1) & 1) * CHUNK, (c + 1) * KC, KC / RPP);
+            if (c + 1 < nchunks) stage(smem + ((c + 1) & 1) * CHUNK, (c + 1) * KC, KC / RPP, bh);
             k_lds = smem + (c & 1) * CHUNK;
             v_lds = k_lds + KC * RB;
             if (active && 2 * c < kend) {
@@ -286,6 +321,40 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
             }
         }
         if (active) finish();
+    } else if constexpr (PD) {
+        const int buf_bytes = 2 * kpad * RB;
+        for (int it = 0; bh < nbh; bh += gridDim.x, ++it) {
+            // head bh has landed in buffer it & 1 (every wave waits for its own pieces, the barrier publishes
+            // them), and every wave is done with head bh - gridDim.x, whose buffer the next head overwrites
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int nxt = bh + gridDim.x;
+            bf16x8 qn[KS];
+            if (nxt < nbh) {                               // workgroup-uniform
+                stage(smem + ((it + 1) & 1) * buf_bytes, 0, kpad / RPP, nxt);
+                load_q(qn, nxt, wave * 32 + r);
+            }
+            k_lds = smem + (it & 1) * buf_bytes;
+            v_lds = k_lds + kpad * RB;
+            q0 = wave * 32;
+            qrow = q0 + r;
+            while (q0 < ntok) {                            // wave-uniform
+                clear_o();
+                m_run = kMaskedScore;
+                l_run = 0.f;
+                int kb = 0;
+                for (; kb + 2 <= kend; kb += 2) key_step(kb, kb, C2{});
+                if (kb < kend) key_step(kb, kb, C1{});
+                finish();
+                q0 += NW * 32;
+                qrow = q0 + r;
+                if (q0 < ntok) load_q(qf, bh, qrow);
+            }
+            if (nxt < nbh) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) qf[ks] = qn[ks];
+            }
+        }
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed
         __syncthreads();
@@ -297,7 +366,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
             q0 += NW * 32;
             qrow = q0 + r;
             if (q0 < ntok) {
-                load_q();
+                load_q(qf, bh, qrow);
                 clear_o();
                 m_run = kMaskedScore;
                 l_run = 0.f;
@@ -306,25 +375,27 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
     }
 }
 
-template <int HD, int NW, bool VTR, bool STREAM>
+template <int HD, int NW, bool VTR, bool STREAM, bool PD = false>
 static hipError_t attn_launch(const void* q, const void* k, const void* v, void* out, int batch, int heads,
                               int ntok, float scale, hipStream_t s) {
     const int kpad = ((ntok + 31) / 32) * 32;
     const int rb = HD == 64 ? 128 : 256;
     const size_t lds = STREAM ? (size_t)4 * 64 * rb
-                              : VTR ? (size_t)kpad * rb * 2 : (size_t)kpad * 128 + (size_t)64 * (kpad + 4) * 2;
+                              : VTR ? (size_t)kpad * rb * (PD ? 4 : 2) + (PD && HD == 64 ? NW * 4096 : 0)
+                                    : (size_t)kpad * 128 + (size_t)64 * (kpad + 4) * 2;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {   // beyond the default dynamic-LDS limit the kernel must be told
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_fwd<HD, NW, VTR, STREAM>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_fwd<HD, NW, VTR, STREAM, PD>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     const int qtiles = (ntok + 31) / 32;
-    dim3 grid(batch * heads, STREAM ? (qtiles + NW - 1) / NW : 1), block(NW * 64);
-    hipLaunchKernelGGL((attention_fwd<HD, NW, VTR, STREAM>), grid, block, lds, s,
+    const int nbh = batch * heads;
+    dim3 grid(PD ? (nbh < num_cus() ? nbh : num_cus()) : nbh, STREAM ? (qtiles + NW - 1) / NW : 1), block(NW * 64);
+    hipLaunchKernelGGL((attention_fwd<HD, NW, VTR, STREAM, PD>), grid, block, lds, s,
                        reinterpret_cast<const bf16_t*>(q), reinterpret_cast<const bf16_t*>(k),
                        reinterpret_cast<const bf16_t*>(v), reinterpret_cast<bf16_t*>(out), ntok, heads,
-                       scale * 1.44269504088896340736f, g_attn_probe);
+                       scale * 1.44269504088896340736f, g_attn_probe, nbh);
     return hipGetLastError();
 }
 
@@ -336,13 +407,16 @@ hipError_t launch_attention(const void* q, const void* k, const void* v, void* o
                             int ntok, int hd, float scale, int variant, hipStream_t s) {
     if ((hd != 64 && hd != 80 && hd != 96) || ntok < 1) return hipErrorInvalidValue;
     const int qtiles = (ntok + 31) / 32;
-    // variant: 0 = automatic (K/V resident in LDS with transposed reads when they fit, else streamed in
-    // 64-key chunks); 1 = resident, V stored transposed (head_dim 64); 2 = streamed
+    // variant: 0 = automatic (persistent workgroups with two resident K/V buffers when two heads fit in LDS,
+    // one head per workgroup when one fits, else K/V streamed in 64-key chunks); 1 = resident, V stored
+    // transposed (head_dim 64); 2 = streamed; 3 = resident, one head per workgroup
     int mode = variant & 3;
     const bool fits = ntok <= (hd == 64 ? 608 : 288);      // 128-byte rows at head_dim 64, 256-byte rows else
-    if (mode == 3 || (mode == 1 && (hd != 64 || !fits))) return hipErrorInvalidValue;
+    const bool fits2 = ntok <= (hd == 64 ? 256 : 160);     // two heads (and the output windows at head_dim 64)
+    if ((mode == 1 && (hd != 64 || !fits)) || (mode == 3 && !fits)) return hipErrorInvalidValue;
     if (mode == 0 && !fits) mode = 2;
-    g_attn_probe = (variant >> 2) & 3;
+    if (mode == 0 && !fits2) mode = 3;
+    g_attn_probe = (variant >> 2) & 7;
     // Waves per workgroup (one 32-row q-tile at a time each).  Resident K/V: one workgroup per head, its
     // waves take q-tiles round-robin; the width with the best balance (q-tiles / (rounds * waves)), the
     // larger on ties.  Streamed: one q-tile per wave, fewest workgroups per head, then fewest idle slots.
@@ -366,11 +440,14 @@ hipError_t launch_attention(const void* q, const void* k, const void* v, void* o
 #define VITK_ATTN_CASE(NWV)                                                                                   \
     case NWV:                                                                                                 \
         if (hd == 96 && mode == 2) return attn_launch<96, NWV, true, true>(q, k, v, out, batch, heads, ntok, scale, s);  \
+        if (hd == 96 && mode == 0) return attn_launch<96, NWV, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s);  \
         if (hd == 96) return attn_launch<96, NWV, true, false>(q, k, v, out, batch, heads, ntok, scale, s);   \
         if (hd == 80 && mode == 2) return attn_launch<80, NWV, true, true>(q, k, v, out, batch, heads, ntok, scale, s);  \
+        if (hd == 80 && mode == 0) return attn_launch<80, NWV, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s);  \
         if (hd == 80) return attn_launch<80, NWV, true, false>(q, k, v, out, batch, heads, ntok, scale, s);   \
         if (mode == 2) return attn_launch<64, NWV, true, true>(q, k, v, out, batch, heads, ntok, scale, s);   \
-        if (mode == 0) return attn_launch<64, NWV, true, false>(q, k, v, out, batch, heads, ntok, scale, s);  \
+        if (mode == 0) return attn_launch<64, NWV, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s);  \
+        if (mode == 3) return attn_launch<64, NWV, true, false>(q, k, v, out, batch, heads, ntok, scale, s);  \
         return attn_launch<64, NWV, false, false>(q, k, v, out, batch, heads, ntok, scale, s);
     switch (nw) {
         VITK_ATTN_CASE(4)
@@ -379,9 +456,11 @@ hipError_t launch_attention(const void* q, const void* k, const void* v, void* o
         VITK_ATTN_CASE(7)
         VITK_ATTN_CASE(8)
         case 10:      // resident modes only
+            // (head_dim 80 / 96 with two resident heads has at most 5 q-tiles: never 10 waves)
             if (hd == 96) return attn_launch<96, 10, true, false>(q, k, v, out, batch, heads, ntok, scale, s);
             if (hd == 80) return attn_launch<80, 10, true, false>(q, k, v, out, batch, heads, ntok, scale, s);
-            if (mode == 0) return attn_launch<64, 10, true, false>(q, k, v, out, batch, heads, ntok, scale, s);
+            if (mode == 0) return attn_launch<64, 10, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s);
+            if (mode == 3) return attn_launch<64, 10, true, false>(q, k, v, out, batch, heads, ntok, scale, s);
             return attn_launch<64, 10, false, false>(q, k, v, out, batch, heads, ntok, scale, s);
     }
 #undef VITK_ATTN_CASE

@@ -157,6 +157,12 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
     // (exact in fp32 sums, same relative rounding in bf16) and most blocks skip the 32-register rescale.
     constexpr float kLazy = 8.0f;
     float m_run = kMaskedScore, l_run = 0.f;
+    // PD: the row sums come from the matrix pipe (the softmax is bound by vector issue, not by MFMA): one more
+    // MFMA per 16-key slice multiplies the packed probabilities with an all-ones V^T block, so every element
+    // of l_acc holds the lane's row sum (of the bf16-rounded probabilities, the same values P.V uses).
+    f32x16 l_acc;
+    const u32x4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
 
     const int kswz = k_swz(r);              // key rows of a block start at multiples of 32: swizzle of r alone
     // transposed-read lane roles: 16-lane group -> d sub-block, lane -> (key row, 4-column piece)
@@ -210,7 +216,12 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
             const float m_new = fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             m_run = m_new;
-            l_run *= alpha;
+            if constexpr (PD) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) l_acc[i] *= alpha;
+            } else {
+                l_run *= alpha;
+            }
 #pragma unroll
             for (int d = 0; d < DB; ++d)
 #pragma unroll
@@ -222,11 +233,60 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 s[u][i] = __builtin_amdgcn_exp2f(fmaf(s[u][i], scale_log2e, -m_run));
-                psum += s[u][i];
+                if constexpr (!PD) psum += s[u][i];
             }
         }
-        l_run += psum;
+        if constexpr (!PD) l_run += psum;
         // O^T[d][q] += V^T[d][key] P^T[key][q]; the packed P^T accumulators are the B operand
+        if constexpr (PD) {
+            // The transposed LDS reads go through inline asm with hand-placed lgkmcnt waits.  Issued through
+            // the builtin, the compiler puts an s_waitcnt vmcnt(0) in front of them for as long as any
+            // LDS-DMA is in flight (it cannot tell that the DMA fills the other buffer), i.e. the first
+            // P.V of a head would wait for the whole staging of the next head.  Groups of 2 DB reads
+            // (one 16-key slice) are issued one group ahead of the MFMAs that use them; the wait is tied to
+            // the group's registers so that the MFMAs cannot move above it.
+            constexpr int G = NB * 2;
+            bf16x4 vv[2][DB][2];
+            auto issue = [&](int g, bf16x4 (&dst)[DB][2]) {
+                const int u = g >> 1, st = g & 1;
+                const int ka = (lb + u) * 32 + 16 * st + 4 * hh + tq;
+#pragma unroll
+                for (int d = 0; d < DB; ++d) {
+                    const int chunk = d * 4 + tsub * 2 + (tp >> 1);
+                    const char* a0 = v_lds + ka * RB + ((chunk ^ v_swz(ka)) << 4) + (tp & 1) * 8;
+                    const uint32_t addr = (uint32_t)(uintptr_t)(lds_void*)a0;
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst[d][0]) : "v"(addr));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst[d][1]) : "v"(addr), "n"(8 * RB));
+                }
+            };
+            auto landed = [&](bf16x4 (&w)[DB][2], auto last_c) {
+                constexpr bool last = decltype(last_c)::value;       // no younger group in flight
+                if constexpr (DB == 2) {
+                    if constexpr (last) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]));
+                    else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]));
+                } else {
+                    if constexpr (last) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[2][0]), "+v"(w[2][1]));
+                    else asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[2][0]), "+v"(w[2][1]));
+                }
+            };
+            issue(0, vv[0]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int u = g >> 1, st = g & 1;
+                if (g + 1 < G) issue(g + 1, vv[(g + 1) & 1]);
+                u32x4 pk = {pack_bf16(s[u][8 * st + 0], s[u][8 * st + 1]), pack_bf16(s[u][8 * st + 2], s[u][8 * st + 3]),
+                            pack_bf16(s[u][8 * st + 4], s[u][8 * st + 5]), pack_bf16(s[u][8 * st + 6], s[u][8 * st + 7])};
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+                if (g + 1 < G) landed(vv[g & 1], std::false_type{});
+                else landed(vv[g & 1], std::true_type{});
+#pragma unroll
+                for (int d = 0; d < DB; ++d) {
+                    const bf16x8 vf = __builtin_shufflevector(vv[g & 1][d][0], vv[g & 1][d][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o_acc[d], 0, 0, 0);
+                }
+                l_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, l_acc, 0, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
 #pragma unroll
@@ -255,6 +315,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
                 }
             }
         }
+        }
     };
     using C1 = std::integral_constant<int, 1>;
     using C2 = std::integral_constant<int, 2>;
@@ -262,7 +323,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
 
     // normalise and store one q-tile: lane holds q = qrow, d = 32*blk + 8g + 4*hh + (0..3)
     auto finish = [&]() {
-        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float l_tot = PD ? l_acc[0] : l_run + __shfl_xor(l_run, 32, 64);
         const float inv = 1.0f / l_tot;
         const int b = bh / heads, h = bh - b * heads;
         if constexpr (PD && HD == 64) {
@@ -326,7 +387,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
         for (int it = 0; bh < nbh; bh += gridDim.x, ++it) {
             // head bh has landed in buffer it & 1 (every wave waits for its own pieces, the barrier publishes
             // them), and every wave is done with head bh - gridDim.x, whose buffer the next head overwrites
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0), through the builtin: the compiler's wait bookkeeping sees it
             __syncthreads();
             const int nxt = bh + gridDim.x;
             bf16x8 qn[KS];
@@ -341,14 +402,20 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
             while (q0 < ntok) {                            // wave-uniform
                 clear_o();
                 m_run = kMaskedScore;
-                l_run = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) l_acc[i] = 0.f;
                 int kb = 0;
                 for (; kb + 2 <= kend; kb += 2) key_step(kb, kb, C2{});
                 if (kb < kend) key_step(kb, kb, C1{});
                 finish();
                 q0 += NW * 32;
                 qrow = q0 + r;
-                if (q0 < ntok) load_q(qf, bh, qrow);
+                if (q0 < ntok) {
+                    // (more q-tiles than waves.)  Waiting here, not at the first use, keeps the key loop free
+                    // of vector-memory waits, which would also wait for the next head's LDS-DMA.
+                    load_q(qf, bh, qrow);
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
+                }
             }
             if (nxt < nbh) {
 #pragma unroll

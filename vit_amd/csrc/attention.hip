@@ -66,6 +66,8 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
     constexpr int CPR = RB / 16;                 // 16-byte slots per LDS row
     constexpr int KC = 64;                       // keys per streamed chunk
     constexpr int CHUNK = 2 * KC * RB;           // bytes of one chunk buffer: K rows, then V rows
+    constexpr bool OVL = PD || STREAM;           // LDS-DMA in flight during the key loop
+    constexpr bool MSUM = OVL || NW > 8;         // row sums on the matrix pipe (16 more registers: not where 4 waves share a SIMD)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -157,10 +159,12 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
     // (exact in fp32 sums, same relative rounding in bf16) and most blocks skip the 32-register rescale.
     constexpr float kLazy = 8.0f;
     float m_run = kMaskedScore, l_run = 0.f;
-    // PD: the row sums come from the matrix pipe (the softmax is bound by vector issue, not by MFMA): one more
+    // MSUM: the row sums come from the matrix pipe (the softmax is bound by vector issue, not by MFMA): one more
     // MFMA per 16-key slice multiplies the packed probabilities with an all-ones V^T block, so every element
     // of l_acc holds the lane's row sum (of the bf16-rounded probabilities, the same values P.V uses).
     f32x16 l_acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) l_acc[i] = 0.f;
     const u32x4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
     const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
 
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
             const float m_new = fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             m_run = m_new;
-            if constexpr (PD) {
+            if constexpr (MSUM) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) l_acc[i] *= alpha;
             } else {
@@ -233,12 +237,12 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 s[u][i] = __builtin_amdgcn_exp2f(fmaf(s[u][i], scale_log2e, -m_run));
-                if constexpr (!PD) psum += s[u][i];
+                if constexpr (!MSUM) psum += s[u][i];
             }
         }
-        if constexpr (!PD) l_run += psum;
+        if constexpr (!MSUM) l_run += psum;
         // O^T[d][q] += V^T[d][key] P^T[key][q]; the packed P^T accumulators are the B operand
-        if constexpr (PD) {
+        if constexpr (OVL) {
             // The transposed LDS reads go through inline asm with hand-placed lgkmcnt waits.  Issued through
             // the builtin, the compiler puts an s_waitcnt vmcnt(0) in front of them for as long as any
             // LDS-DMA is in flight (it cannot tell that the DMA fills the other buffer), i.e. the first
@@ -313,6 +317,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
                     const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
                     o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o_acc[d], 0, 0, 0);
                 }
+                if constexpr (MSUM) l_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, l_acc, 0, 0, 0);
             }
         }
         }
@@ -323,7 +328,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
 
     // normalise and store one q-tile: lane holds q = qrow, d = 32*blk + 8g + 4*hh + (0..3)
     auto finish = [&]() {
-        const float l_tot = PD ? l_acc[0] : l_run + __shfl_xor(l_run, 32, 64);
+        const float l_tot = MSUM ? l_acc[0] : l_run + __shfl_xor(l_run, 32, 64);
         const float inv = 1.0f / l_tot;
         const int b = bh / heads, h = bh - b * heads;
         if constexpr (PD && HD == 64) {
@@ -367,11 +372,13 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
 
     if constexpr (STREAM) {
         const bool active = q0 < ntok;   // wave-uniform: a wave whose whole q-tile is padding only takes part in staging
+#pragma unroll
+        for (int i = 0; i < 16; ++i) l_acc[i] = 0.f;
         const int nchunks = (kblocks + 1) >> 1;
         for (int c = 0; c < nchunks; ++c) {
             // chunk c has landed (every wave waits for its own pieces, the barrier publishes them), and
             // every wave is done reading chunk c-1, whose buffer chunk c+1 now overwrites
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0)
             __syncthreads();
             if (c + 1 < nchunks) stage(smem + ((c + 1) & 1) * CHUNK, (c + 1) * KC, KC / RPP, bh);
             k_lds = smem + (c & 1) * CHUNK;
@@ -437,6 +444,8 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
                 clear_o();
                 m_run = kMaskedScore;
                 l_run = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) l_acc[i] = 0.f;
             }
         }
     }

@@ -57,3 +57,31 @@ def test_checkpoint_at_224_loads_into_a_384_model():
     with torch.no_grad():
         y = m.eval()(x)
     assert y.shape == (1, 1000) and torch.isfinite(y).all()
+
+
+def test_adapt_state_dict_head_reset_on_cpu():
+    """load_checkpoint's --pretrained edits (utils.py:224-233); same resolution, so no resampling (and no GPU)."""
+    import vit_amd
+    sd = {"pos_embed": torch.zeros(1, 197, 8), "head.weight": torch.ones(21843, 8), "head.bias": torch.ones(21843),
+          "pre_logits.weight": torch.ones(8, 8), "pre_logits.bias": torch.ones(8), "cls_token": torch.zeros(1, 1, 8)}
+    pe = sd["pos_embed"]
+    out = vit_amd.adapt_state_dict({"state_dict": sd, "epoch": 3}, img_size=224, num_classes=10, pretrained=True)
+    assert out is sd and out["pos_embed"] is pe
+    assert out["head.weight"].shape == (10, 8) and not out["head.weight"].any() and out["head.bias"].shape == (10,)
+    assert "pre_logits.weight" not in out and "pre_logits.bias" not in out
+    sd2 = {"pos_embed": pe, "head.weight": torch.ones(5, 8), "head.bias": torch.ones(5), "pre_logits.weight": torch.ones(8, 8)}
+    out2 = vit_amd.adapt_state_dict(sd2, img_size=224, num_classes=10)
+    assert out2["head.weight"].shape == (5, 8) and "pre_logits.weight" in out2          # untouched without pretrained
+
+
+@pytest.mark.gpu
+def test_adapt_state_dict_fine_tune_start_at_384():
+    import vit_amd
+    from vit_amd import synth
+    sd = dict(synth.synth_state_dict(synth.ARCHS["s16"], 224, seed=0))
+    sd = vit_amd.adapt_state_dict({"state_dict": sd}, img_size=384, num_classes=10, pretrained=True)
+    m = vit_amd.s16(img_size=384, num_classes=10, pre_logits=False).cuda().eval()
+    m.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        y = m(synth.synth_images(2, 384, seed=1).cuda())
+    assert y.shape == (2, 10) and not y.any()                                             # zero head: zero logits

@@ -71,3 +71,21 @@ def pos_embed_scale(pos_embed, img_size, patch_size, mode='constant', order=1):
         _lib.check(L.vitk_pos_embed_scale(src.data_ptr(), out.data_ptr(), g, G, D,
                                           torch.cuda.current_stream().cuda_stream), L)
     return out.to(device=pos_embed.device, dtype=pos_embed.dtype)
+
+
+def adapt_state_dict(state_dict, img_size, num_classes=1000, pretrained=False, patch_size=16):
+    """The state_dict edits of the reference's load_checkpoint (utils.py:211-235), without its file and
+    optimizer handling: a checkpoint dict is unwrapped to its 'state_dict'; with `pretrained` the head is
+    replaced by zeros of [num_classes, hidden] and the pre_logits layer is dropped (fine-tuning start, so the
+    model must be built with pre_logits=False); pos_embed is rescaled to the model's grid.  Returns the
+    (modified in place, as in the reference) state_dict, ready for a strict load_state_dict."""
+    if 'state_dict' in state_dict:
+        state_dict = state_dict['state_dict']
+    if pretrained:
+        hidden_width = state_dict['head.weight'].shape[1]
+        state_dict['head.weight'] = torch.zeros(num_classes, hidden_width)
+        state_dict['head.bias'] = torch.zeros(num_classes)
+        state_dict.pop('pre_logits.weight', None)
+        state_dict.pop('pre_logits.bias', None)
+    state_dict['pos_embed'] = pos_embed_scale(state_dict['pos_embed'], img_size=img_size, patch_size=patch_size)
+    return state_dict

@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
                     help="compute mode; the headline metric is bf16, fp32 is the reference-accuracy mode")
+    ap.add_argument("--mode", default="fwd", choices=["fwd", "train"],
+                    help="fwd: the headline forward benchmark; train: one training step per timed step "
+                         "(forward, CrossEntropyLoss, backward, clip_grad_norm_ 1.0, AdamW; main.py:207-223 of the reference)")
     a = ap.parse_args()
 
     # Rehearsal switches for a box with fewer GPUs than ranks (never set by the real launch): the ranks
@@ -125,16 +128,42 @@ def main():
     timer = KernelTimer("gemm_bias_gelu" if a.precision == "bf16" else "attention_f32")
     ops.set_event_hook(timer)
 
-    with torch.no_grad():
+    if a.mode == "train":
+        # BASELINE configs[4]: the reference's step with its defaults (run.py:55-60, 224: AdamW lr 1e-3,
+        # weight_decay 0.03, gradient_clip 1.0); gradients all-reduced over RCCL by DistributedDataParallel
+        # as in main.py:125-126
+        model.train()
+        net = model
+        if world > 1 and not share:
+            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True)
+        opt = torch.optim.AdamW(model.parameters(), 1e-3, weight_decay=0.03, fused=True)
+        crit = torch.nn.CrossEntropyLoss()
+        target = torch.randint(0, 1000, (a.batch,), device=dev, generator=torch.Generator(device=dev).manual_seed(rank))
+
+        def step():
+            out = net(x)
+            loss = crit(out, target)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            return out.detach()
+        ctx = torch.enable_grad()
+    else:
+        def step():
+            return model(x)
+        ctx = torch.no_grad()
+
+    with ctx:
         for _ in range(a.warmup):
-            model(x)
+            step()
         torch.cuda.synchronize()
         vdist.barrier()
         torch.cuda.synchronize()
         timer.enabled = True
         t0 = time.perf_counter()
         for _ in range(a.steps):
-            y = model(x)
+            y = step()
         torch.cuda.synchronize()
         vdist.barrier()
         torch.cuda.synchronize()
@@ -152,17 +181,20 @@ def main():
         k_ms = timer.mean_ms()
         achieved = k_flops / (k_ms * 1e-3) / 1e12
         out = {
-            "metric": f"images/sec (whole node) ViT-{a.arch.upper()[0]}/{cfg['patches']} {a.img_size}px {a.precision} fwd",
+            "metric": f"images/sec (whole node) ViT-{a.arch.upper()[0]}/{cfg['patches']} {a.img_size}px {a.precision} "
+                      + ("fwd" if a.mode == "fwd" else "train step"),
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if a.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"ViT-{a.arch.upper()[0]}/{cfg['patches']} {a.img_size}px forward, "
-                                   f"batch {a.batch} per GPU, random-init weights"
-                                   + (" (BASELINE configs[1])" if (a.arch, a.img_size, a.batch) == ("b16", 224, 256) else ""),
+            "config": {"workload": f"ViT-{a.arch.upper()[0]}/{cfg['patches']} {a.img_size}px "
+                                   + ("forward, " if a.mode == "fwd" else "training step (fwd kernels + torch backward, CE, clip 1.0, AdamW), ")
+                                   + f"batch {a.batch} per GPU, random-init weights"
+                                   + (" (BASELINE configs[1])" if (a.mode, a.arch, a.img_size, a.batch) == ("fwd", "b16", 224, 256) else ""),
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world, "tokens": ntok,
-                       "parallelism": f"dp{world}: batch sharded, weights replicated, no collectives"},
+                       "parallelism": f"dp{world}: batch sharded, weights replicated, "
+                                      + ("no collectives" if a.mode == "fwd" else "gradient all-reduce over RCCL (DDP)")},
             "gflop_per_image": round(F / 1e9, 3),
-            "mfma_peak_frac": round(value * F / (world * MFMA_BF16_PEAK), 4),
+            "mfma_peak_frac": round(value * F * (1 if a.mode == "fwd" else 3) / (world * MFMA_BF16_PEAK), 4),
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_pp<bias+GELU> (fc1)",
                          "achieved": round(achieved, 1), "peak": round(MFMA_BF16_PEAK / 1e12, 1),
                          "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_BF16_PEAK, 4),
@@ -173,7 +205,9 @@ def main():
         }
         if a.precision != "bf16":
             out.pop("roofline")          # the roofline entry describes the bf16 fc1 kernel only
-        if world == 1 and not a.no_cpu_baseline:
+        if a.mode == "train":
+            out["train_flop_factor"] = 3          # forward + 2 x forward for the backward GEMMs
+        if world == 1 and not a.no_cpu_baseline and a.mode == "fwd":
             out["cpu_baseline"] = cpu_baseline(a.arch, a.img_size, sd, 32 if a.img_size <= 224 else 8)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -226,8 +226,42 @@ def accuracy_fixture():
     print("accuracy", len(cases), "cases")
 
 
+def train_fixture():
+    """Loss, logits and parameter gradients of one training step (main.py:207-218: CrossEntropyLoss, backward)
+    of the reference model class on a small configuration with synthetic weights.  Gradients are stored
+    subsampled (every `STRIDE`-th element of the flattened tensor) with each tensor's full L2 norm."""
+    from oracle import train_oracle as to
+    cfg = to.SMALL
+    sd = synth.synth_state_dict(cfg, to.SMALL_IMG, seed=5, style="perturbed", num_classes=to.SMALL_CLASSES)
+    m = ref_vt.VisionTransformer(img_size=to.SMALL_IMG, patches=cfg["patches"], num_classes=to.SMALL_CLASSES,
+                                 hidden_size=cfg["hidden_size"], num_layers=cfg["num_layers"],
+                                 num_heads=cfg["num_heads"], mlp_ratio=cfg["mlp_ratio"],
+                                 norm=partial(torch.nn.LayerNorm, eps=cfg["eps"])).train()
+    m.load_state_dict(sd, strict=True)
+    x = synth.synth_images(to.SMALL_BATCH, to.SMALL_IMG, seed=6)
+    target = torch.tensor([3, 1, 4, 1, 5, 9])
+    logits = m(x)
+    loss = torch.nn.CrossEntropyLoss()(logits, target)
+    loss.backward()
+    total = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)          # main.py:221-223; returns the norm before clipping
+    STRIDE = 7
+    out = {"logits": np_(logits), "loss": np.array(float(loss)), "target": np_(target), "total_norm": np.array(float(total))}
+    coef = min(1.0, 1.0 / (float(total) + 1e-6))
+    for k, p in m.named_parameters():
+        g = p.grad / coef                                                  # undo the clip: store raw gradients
+        out["gnorm." + k] = np.array(float(g.norm()))
+        out["g." + k] = np_(g.reshape(-1)[::STRIDE])
+    np.savez_compressed(os.path.join(HERE, "train_small.npz"), **out)
+    with open(os.path.join(HERE, "train_small.json"), "w") as f:
+        json.dump({"stride": STRIDE, "seed": 5, "image_seed": 6, "n_params": len(list(m.parameters()))}, f)
+    print("train_small loss %.6f total grad norm %.4f" % (float(loss), float(total)))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if sys.argv[1:] == ["train"]:
+        train_fixture()
+        sys.exit(0)
     if sys.argv[1:] == ["accuracy"]:
         accuracy_fixture()
         sys.exit(0)

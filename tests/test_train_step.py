@@ -1,0 +1,114 @@
+"""One training step (main.py:207-223 of the reference: forward, CrossEntropyLoss, backward, clip_grad_norm_,
+optimizer step).  CPU: the oracle against loss / logits / gradients captured from the reference model class
+under torch autograd.  GPU: the model's autograd path (forward kernels + torch backward) against the same
+vectors, near-exact in the fp32 mode and to bf16 accuracy in the default mode."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import train_oracle as to
+from tests.helpers import load_golden
+from vit_amd import synth
+
+
+def _setup():
+    meta, g = load_golden("train_small")
+    sd = synth.synth_state_dict(to.SMALL, to.SMALL_IMG, seed=meta["seed"], style="perturbed", num_classes=to.SMALL_CLASSES)
+    x = synth.synth_images(to.SMALL_BATCH, to.SMALL_IMG, seed=meta["image_seed"])
+    return meta, g, sd, x, torch.from_numpy(g["target"])
+
+
+def _check_grads(grads, g, stride, rel_tol, cos_min):
+    worst = 0.0
+    for k, want_sub in ((k[2:], v) for k, v in g.items() if k.startswith("g.")):
+        got = grads[k].detach().float().cpu()
+        want_norm = float(g["gnorm." + k])
+        got_sub = got.reshape(-1)[::stride].numpy()
+        err = np.linalg.norm(got_sub - want_sub) / max(np.linalg.norm(want_sub), 1e-12)
+        cos = float(np.dot(got_sub, want_sub) / max(np.linalg.norm(got_sub) * np.linalg.norm(want_sub), 1e-20))
+        assert err <= rel_tol and cos >= cos_min, f"{k}: relative error {err:.3e}, cosine {cos:.6f}"
+        assert abs(float(got.norm()) - want_norm) <= rel_tol * want_norm + 1e-12, f"{k}: norm"
+        worst = max(worst, err)
+    return worst
+
+
+def test_oracle_training_step_matches_reference_vectors():
+    meta, g, sd, x, target = _setup()
+    loss, logits, grads = to.loss_and_grads(sd, x, target, to.SMALL)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-6
+    assert np.abs(logits.numpy() - g["logits"]).max() <= 2e-5
+    assert len(grads) == meta["n_params"]
+    _check_grads(grads, g, meta["stride"], 1e-4, 0.999999)
+    coef, total = to.clip_coefficient(grads, 1.0)
+    assert abs(float(total) - float(g["total_norm"])) <= 1e-4 * float(g["total_norm"])
+    assert 0.0 < float(coef) < 1.0                                        # the fixture's step is clipped
+
+
+def _model(precision):
+    import vit_amd
+    cfg = to.SMALL
+    m = vit_amd.VisionTransformer(img_size=to.SMALL_IMG, patches=cfg["patches"], num_classes=to.SMALL_CLASSES,
+                                  hidden_size=cfg["hidden_size"], num_layers=cfg["num_layers"],
+                                  num_heads=cfg["num_heads"], mlp_ratio=cfg["mlp_ratio"],
+                                  norm=lambda d: torch.nn.LayerNorm(d, eps=cfg["eps"]), precision=precision)
+    return m.cuda().train()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,logit_tol,rel_tol,cos_min", [("fp32", 2e-5, 2e-4, 0.99999), ("bf16", 1e-2, 4e-2, 0.999)])
+def test_gpu_gradients_match_reference_vectors(precision, logit_tol, rel_tol, cos_min):
+    meta, g, sd, x, target = _setup()
+    m = _model(precision)
+    m.load_state_dict(sd, strict=True)
+    logits = m(x.cuda())
+    assert logits.requires_grad and logits.dtype == torch.float32
+    loss = torch.nn.CrossEntropyLoss()(logits, target.cuda())
+    loss.backward()
+    err = np.abs(logits.detach().cpu().numpy() - g["logits"]).max()
+    assert err <= logit_tol, f"logits {err:.3e}"
+    assert abs(float(loss) - float(g["loss"])) <= logit_tol
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    assert all(v is not None for v in grads.values())
+    worst = _check_grads(grads, g, meta["stride"], rel_tol, cos_min)
+    total = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+    assert abs(float(total) - float(g["total_norm"])) <= rel_tol * float(g["total_norm"])
+    print(f"{precision}: logits {err:.3e}, worst relative gradient error {worst:.3e}")
+    with torch.no_grad():                                                 # the inference path gives the same logits
+        assert torch.equal(m(x.cuda()), logits.detach())
+
+
+@pytest.mark.gpu
+def test_gpu_training_steps_reduce_the_loss_and_refresh_the_weight_cache():
+    meta, g, sd, x, target = _setup()
+    m = _model("bf16")
+    m.load_state_dict(sd, strict=True)
+    opt = torch.optim.AdamW(m.parameters(), 1e-3, weight_decay=0.03)      # run.py:55-60
+    crit = torch.nn.CrossEntropyLoss()
+    xs, ts = x.cuda(), target.cuda()
+    losses = []
+    for _ in range(6):
+        loss = crit(m(xs), ts)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        opt.step()
+        opt.zero_grad()
+        losses.append(float(loss))
+    assert abs(losses[0] - float(g["loss"])) <= 1e-2
+    assert losses[-1] < losses[0] - 0.5, losses                            # six steps on one batch: it is being fitted
+    m.eval()
+    with torch.no_grad():
+        assert abs(float(crit(m(xs), ts)) - losses[-1]) < 1.0               # kernels see the updated weights
+
+
+@pytest.mark.gpu
+def test_gpu_uint8_images_and_dropout_guard():
+    import vit_amd
+    m = _model("bf16")
+    x8 = torch.randint(0, 256, (2, 3, to.SMALL_IMG, to.SMALL_IMG), dtype=torch.uint8).cuda()
+    y = m(x8)
+    y.sum().backward()
+    assert m.head.weight.grad is not None and torch.isfinite(m.embedding.weight.grad).all()
+    bad = vit_amd.VisionTransformer(img_size=32, patches=8, num_classes=10, hidden_size=256, num_layers=1,
+                                    num_heads=4, dropout=0.1).cuda().train()
+    with pytest.raises(vit_amd.VitkError):
+        bad(torch.zeros(1, 3, 32, 32).cuda())

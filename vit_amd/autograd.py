@@ -1,0 +1,230 @@
+"""Training path: the forward kernels as torch.autograd.Functions.
+
+The reference trains the same module it evaluates (main.py:207-223: `loss = criterion(model(images),
+target); loss.backward(); clip_grad_norm_; optimizer.step()`).  Here every forward op is still a libvitk
+kernel; each Function keeps what its backward needs and computes the gradients with torch operations on
+the GPU (library GEMMs, aten backward ops), recomputing cheap intermediates instead of storing them.
+Gradients arrive at the module's ordinary fp32 Parameters, so optimizers, `clip_grad_norm_` and
+DistributedDataParallel work unchanged.  No backward kernel is hand-written yet.
+
+cd = compute dtype of the GEMM operands: torch.bfloat16, or torch.float32 in the fp32 mode.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .lib import EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_TANH, VitkError
+
+
+def _vjp(fn, inputs, grad_out):
+    """Gradients of fn(*inputs) w.r.t. inputs (detached copies), by recomputing fn with torch."""
+    with torch.enable_grad():
+        ins = [t.detach().requires_grad_(True) for t in inputs]
+        out = fn(*ins)
+        return torch.autograd.grad(out, ins, grad_out)
+
+
+class LayerNormFn(torch.autograd.Function):
+    """y = LayerNorm(x) in cd; x f32 [rows, D] (models/transformer.py:68,73,98)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, cd):
+        out = torch.empty(x.shape, dtype=cd, device=x.device)
+        ops.layernorm(x, weight.detach(), bias.detach(), eps, out)
+        ctx.save_for_backward(x, weight, bias)
+        ctx.eps = eps
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, bias = ctx.saved_tensors
+        D = x.shape[-1]
+        gx, gw, gb = _vjp(lambda a, w, b: F.layer_norm(a, (D,), w, b, ctx.eps), (x, weight, bias), g.float())
+        return gx, gw, gb, None, None
+
+
+def _linear_backward(g_pre, a, w_cd, weight, bias):
+    """g_pre [rows, out] in cd -> (grad a [rows, in] in cd, grad weight f32, grad bias f32)."""
+    ga = g_pre @ w_cd
+    gw = (g_pre.t() @ a).to(weight.dtype)
+    gb = None if bias is None else g_pre.sum(0, dtype=torch.float32).to(bias.dtype)
+    return ga, gw, gb
+
+
+class LinearFn(torch.autograd.Function):
+    """out = epilogue(a W^T + b).  kind: 'bias' (cd out), 'gelu' (cd), 'tanh' (cd), 'logits' (f32 out),
+    'resid' (f32 out = resid + a W^T + b).  w_cd is the kernel-ready copy of `weight` in cd."""
+
+    @staticmethod
+    def forward(ctx, a, weight, bias, w_cd, kind, resid):
+        rows, n = a.shape[0], weight.shape[0]
+        cd = a.dtype
+        b32 = None if bias is None else bias.detach()
+        fp32 = cd == torch.float32
+        out_dtype = torch.float32 if kind in ("resid", "logits") else cd
+        out = torch.empty(rows, n, dtype=out_dtype, device=a.device)
+        if fp32:
+            epi = {"bias": EPI_BIAS, "logits": EPI_BIAS, "gelu": EPI_GELU, "tanh": EPI_TANH, "resid": EPI_RESIDUAL}[kind]
+            ops.gemm_f32(a, w_cd, b32, out, epi, resid=resid if kind == "resid" else None)
+        elif kind == "gelu":
+            ops.gemm_bias_gelu(a, w_cd, b32, out)
+        elif kind == "tanh":
+            ops.gemm_bias_tanh(a, w_cd, b32, out)
+        elif kind == "resid":
+            ops.gemm_bias_residual(a, w_cd, b32, resid, out)
+        else:
+            ops.gemm_bias(a, w_cd, b32, out)
+        ctx.kind = kind
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(a, weight, bias, w_cd, out if kind == "tanh" else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, weight, bias, w_cd, out = ctx.saved_tensors
+        cd = a.dtype
+        g_resid = g if ctx.kind == "resid" else None
+        if ctx.kind == "gelu":
+            # the pre-activation is recomputed (one library GEMM) instead of being stored by the forward
+            pre = F.linear(a, w_cd, None if bias is None else bias.to(cd))
+            g_pre = torch.ops.aten.gelu_backward(g, pre)                      # f32 math inside, cd in and out
+        elif ctx.kind == "tanh":
+            o = out.float()
+            g_pre = (g.float() * (1.0 - o * o)).to(cd)
+        else:
+            g_pre = g.to(cd)
+        ga, gw, gb = _linear_backward(g_pre, a, w_cd, weight, bias)
+        return ga, gw, gb, None, None, g_resid
+
+
+class QkvFn(torch.autograd.Function):
+    """qkv [3, B, H, N, hd] = head-major split of a W_in^T + b (models/transformer.py:42)."""
+
+    @staticmethod
+    def forward(ctx, a, weight, bias, w_cd, B, N, H, hd):
+        qkv = torch.empty(3, B, H, N, hd, dtype=a.dtype, device=a.device)
+        b32 = None if bias is None else bias.detach()
+        if a.dtype == torch.float32:
+            ops.qkv_proj_f32(a, w_cd, b32, qkv, B, N, H, hd)
+        else:
+            ops.qkv_proj(a, w_cd, b32, qkv, B, N, H, hd)
+        ctx.save_for_backward(a, weight, bias, w_cd)
+        return qkv
+
+    @staticmethod
+    def backward(ctx, g):
+        a, weight, bias, w_cd = ctx.saved_tensors
+        _, B, H, N, hd = g.shape
+        g_pre = g.permute(1, 3, 0, 2, 4).reshape(B * N, 3 * H * hd)        # back to [rows, which*D + h*hd + e]
+        ga, gw, gb = _linear_backward(g_pre, a, w_cd, weight, bias)
+        return ga, gw, gb, None, None, None, None, None
+
+
+def _attention_torch(qkv, scale):
+    q, k, v = qkv[0], qkv[1], qkv[2]                                       # [B, H, N, hd]
+    if qkv.dtype == torch.float32:
+        s = (q @ k.transpose(-2, -1)) * scale
+        o = s.softmax(-1) @ v
+    else:
+        o = F.scaled_dot_product_attention(q, k, v, scale=scale)           # torch's fused kernel where it has one
+    B, H, N, hd = o.shape
+    return o.transpose(1, 2).reshape(B, N, H * hd)
+
+
+class AttentionFn(torch.autograd.Function):
+    """ctx [B, N, H*hd] = softmax(q k^T scale) v, heads concatenated (models/transformer.py:43-46)."""
+
+    @staticmethod
+    def forward(ctx, qkv, scale):
+        _, B, H, N, hd = qkv.shape
+        out = torch.empty(B, N, H * hd, dtype=qkv.dtype, device=qkv.device)
+        if qkv.dtype == torch.float32:
+            ops.attention_f32(qkv, out, scale)
+        else:
+            ops.attention(qkv, out, scale)
+        ctx.save_for_backward(qkv)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (qkv,) = ctx.saved_tensors
+        (gq,) = _vjp(lambda t: _attention_torch(t, ctx.scale), (qkv,), g)
+        return gq, None
+
+
+def _embed_torch(img, weight, bias, cls, pos, patch):
+    x = F.conv2d(img, weight.to(img.dtype), None, stride=patch).float()    # [B, D, gh, gw]
+    x = x.flatten(2).transpose(1, 2) + bias                                # [B, n, D]
+    x = torch.cat((cls.expand(x.shape[0], -1, -1), x), dim=1)
+    return x + pos
+
+
+class PatchEmbedFn(torch.autograd.Function):
+    """x f32 [B, N, D] = cat(cls, conv(img) + bias) + pos (models/vision_transformer.py:47-50)."""
+
+    @staticmethod
+    def forward(ctx, img, weight, bias, cls, pos, w_cd, b32, cls32, pos32, patch, cols):
+        B = img.shape[0]
+        N, D = pos32.shape
+        x = torch.empty(B, N, D, dtype=torch.float32, device=img.device)
+        if img.dtype == torch.float32:
+            ops.patch_embed_f32(img, w_cd, b32, cls32, pos32, x, patch)
+        elif cols is None:
+            ops.patch_embed(img, w_cd, b32, cls32, pos32, x, patch)
+        else:
+            ops.patch_embed_cols(img, w_cd, b32, cls32, pos32, x, cols, patch)
+        ctx.save_for_backward(img, weight, bias, cls, pos)
+        ctx.patch = patch
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        img, weight, bias, cls, pos = ctx.saved_tensors
+        with torch.enable_grad():
+            ins = [t.detach().requires_grad_(True) for t in (weight, bias, cls, pos)]
+            out = _embed_torch(img, *ins, ctx.patch)
+            gw, gb, gc, gp = torch.autograd.grad(out, ins, g)
+        return None, gw, gb, gc, gp, None, None, None, None, None, None
+
+
+def forward_train(model, x):
+    """The forward of vit_amd.VisionTransformer with autograd: same kernels, fresh tensors per op."""
+    w = model._cache.get()
+    fp32 = model.precision == "fp32"
+    cd = torch.float32 if fp32 else torch.bfloat16
+    B, _, Hi, Wi = x.shape
+    P = model.patches
+    N = (Hi // P) * (Wi // P) + 1
+    D, H = model.hidden_size, model.num_heads
+    hd = D // H
+    if x.dtype == torch.uint8:
+        img = ops.normalize_u8(x.contiguous(), model.pixel_mean, model.pixel_std,
+                               torch.empty(x.shape, dtype=cd, device=x.device))
+    elif x.dtype in (torch.float32, torch.bfloat16):
+        img = x.to(cd).contiguous()
+    else:
+        raise VitkError(f"unsupported image dtype {x.dtype}")
+    cols = None
+    if not fp32 and w["embed.w"].shape[1] != 3 * P * P:                    # explicit patch matrix (non-power-of-two patch)
+        cols = torch.empty(B * (N - 1), w["embed.w"].shape[1], dtype=torch.bfloat16, device=x.device)
+    xs = PatchEmbedFn.apply(img, model.embedding.weight, model.embedding.bias, model.cls_token, model.pos_embed,
+                            w["embed.w"], w["embed.b"], w["cls"], w["pos"], P, cols)
+    x2 = xs.view(B * N, D)
+    for i, blk in enumerate(model.encoder.blocks):
+        p = f"b{i}."
+        att, mlp = blk.attention, blk.mlp
+        y = LayerNormFn.apply(x2, blk.norm1.weight, blk.norm1.bias, float(blk.norm1.eps), cd)
+        qkv = QkvFn.apply(y, att.in_proj.weight, att.in_proj.bias, w[p + "qkv.w"], B, N, H, hd)
+        ctxt = AttentionFn.apply(qkv, att.scaling)
+        x2 = LinearFn.apply(ctxt.view(B * N, D), att.out_proj.weight, att.out_proj.bias, w[p + "out.w"], "resid", x2)
+        y = LayerNormFn.apply(x2, blk.norm2.weight, blk.norm2.bias, float(blk.norm2.eps), cd)
+        h = LinearFn.apply(y, mlp.fc1.weight, mlp.fc1.bias, w[p + "fc1.w"], "gelu", None)
+        x2 = LinearFn.apply(h, mlp.fc2.weight, mlp.fc2.bias, w[p + "fc2.w"], "resid", x2)
+    cls_rows = x2.view(B, N, D)[:, 0].contiguous()                         # the reference keeps token 0 (transformer.py:99)
+    norm = model.encoder.norm
+    feat = LayerNormFn.apply(cls_rows, norm.weight, norm.bias, float(norm.eps), cd)
+    if "pre.w" in w:
+        feat = LinearFn.apply(feat, model.pre_logits.weight, model.pre_logits.bias, w["pre.w"], "tanh", None)
+    logits = LinearFn.apply(feat, model.head.weight, model.head.bias, w["head.w"], "logits", None)
+    return logits.to(model.head.weight.dtype)

@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .autograd import forward_train
 from .engine import WeightCache, Workspace, gather_patch_ok
 from .lib import EPI_TANH, VitkError
 from .transformer import Encoder
@@ -95,8 +96,6 @@ class VisionTransformer(nn.Module):
             raise VitkError("VisionTransformer.forward needs a CUDA/HIP tensor: this path has no CPU fallback")
         if x.dim() != 4 or x.shape[1] != 3:
             raise VitkError(f"expected images [B,3,H,W], got {tuple(x.shape)}")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise VitkError("forward-only path: call under torch.no_grad() (backward kernels are not built yet)")
         if self.training and self._p_dropout > 0.:
             raise VitkError("dropout > 0 in training mode is not implemented on this path")
         w = self._cache.get()
@@ -107,6 +106,9 @@ class VisionTransformer(nn.Module):
         N = (Hi // P) * (Wi // P) + 1
         if N != w["pos"].shape[0]:
             raise VitkError(f"input {Hi}x{Wi} gives {N} tokens but pos_embed holds {w['pos'].shape[0]}")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # training (main.py:207-223): the same kernels as autograd Functions, fresh tensors per op
+            return forward_train(self, x)
         ws = self._workspace(x.device, B, N)
         out_dtype = self.head.weight.dtype
 

@@ -112,3 +112,26 @@ def test_gpu_uint8_images_and_dropout_guard():
                                     num_heads=4, dropout=0.1).cuda().train()
     with pytest.raises(vit_amd.VitkError):
         bad(torch.zeros(1, 3, 32, 32).cuda())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,D", [(1, 256), (7, 768), (1000, 768), (4099, 1024), (50432, 768), (33, 1280)])
+@pytest.mark.parametrize("gdt", [torch.float32, torch.bfloat16])
+def test_gpu_layernorm_backward_kernel(rows, D, gdt):
+    """vitk_layernorm_backward against torch autograd of F.layer_norm in fp64 on the same inputs."""
+    from vit_amd import ops
+    gen = torch.Generator().manual_seed(rows + D)
+    x = torch.randn(rows, D, generator=gen) * 1.7 + 0.3
+    gamma = 1.0 + 0.1 * torch.randn(D, generator=gen)
+    beta = 0.1 * torch.randn(D, generator=gen)
+    g = torch.randn(rows, D, generator=gen).to(gdt)
+    xd, gd_, bd = (t.double().requires_grad_(True) for t in (x, gamma, beta))
+    y = torch.nn.functional.layer_norm(xd, (D,), gd_, bd, 1e-6)
+    wx, wg, wb = torch.autograd.grad(y, (xd, gd_, bd), g.double())
+    dx, dg, db = ops.layernorm_backward(x.cuda(), gamma.cuda(), g.cuda(), 1e-6)
+    assert torch.allclose(dx.cpu().double(), wx, rtol=1e-4, atol=2e-5)
+    scale = max(1.0, rows ** 0.5)
+    assert (dg.cpu().double() - wg).abs().max() <= 2e-5 * scale
+    assert (db.cpu().double() - wb).abs().max() <= 2e-5 * scale
+    dx2, dg2, db2 = ops.layernorm_backward(x.cuda(), gamma.cuda(), g.cuda(), 1e-6)
+    assert torch.equal(dg, dg2) and torch.equal(db, db2) and torch.equal(dx, dx2)      # fixed summation order

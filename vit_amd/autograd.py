@@ -5,7 +5,7 @@ target); loss.backward(); clip_grad_norm_; optimizer.step()`).  Here every forwa
 kernel; each Function keeps what its backward needs and computes the gradients with torch operations on
 the GPU (library GEMMs, aten backward ops), recomputing cheap intermediates instead of storing them.
 Gradients arrive at the module's ordinary fp32 Parameters, so optimizers, `clip_grad_norm_` and
-DistributedDataParallel work unchanged.  No backward kernel is hand-written yet.
+DistributedDataParallel work unchanged.  Hand-written backward kernels so far: LayerNorm.
 
 cd = compute dtype of the GEMM operands: torch.bfloat16, or torch.float32 in the fp32 mode.
 """
@@ -38,9 +38,8 @@ class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, weight, bias = ctx.saved_tensors
-        D = x.shape[-1]
-        gx, gw, gb = _vjp(lambda a, w, b: F.layer_norm(a, (D,), w, b, ctx.eps), (x, weight, bias), g.float())
-        return gx, gw, gb, None, None
+        gx, gw, gb = ops.layernorm_backward(x, weight.detach(), g.contiguous(), ctx.eps)
+        return gx, gw.to(weight.dtype), gb.to(bias.dtype), None, None
 
 
 def _linear_backward(g_pre, a, w_cd, weight, bias):
@@ -85,8 +84,12 @@ class LinearFn(torch.autograd.Function):
         cd = a.dtype
         g_resid = g if ctx.kind == "resid" else None
         if ctx.kind == "gelu":
-            # the pre-activation is recomputed (one library GEMM) instead of being stored by the forward
-            pre = F.linear(a, w_cd, None if bias is None else bias.to(cd))
+            # the pre-activation is recomputed (one more GEMM) instead of being stored by the forward
+            if cd == torch.bfloat16:
+                pre = torch.empty(a.shape[0], weight.shape[0], dtype=cd, device=a.device)
+                ops.gemm_bias(a, w_cd, None if bias is None else bias.detach(), pre)
+            else:
+                pre = F.linear(a, w_cd, bias)
             g_pre = torch.ops.aten.gelu_backward(g, pre)                      # f32 math inside, cd in and out
         elif ctx.kind == "tanh":
             o = out.float()
@@ -120,9 +123,9 @@ class QkvFn(torch.autograd.Function):
         return ga, gw, gb, None, None, None, None, None
 
 
-def _attention_torch(qkv, scale):
-    q, k, v = qkv[0], qkv[1], qkv[2]                                       # [B, H, N, hd]
-    if qkv.dtype == torch.float32:
+def _attention_torch(q, k, v, scale):
+    """[B, H, N, hd] each -> [B, N, H*hd]."""
+    if q.dtype == torch.float32:
         s = (q @ k.transpose(-2, -1)) * scale
         o = s.softmax(-1) @ v
     else:
@@ -149,8 +152,13 @@ class AttentionFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (qkv,) = ctx.saved_tensors
-        (gq,) = _vjp(lambda t: _attention_torch(t, ctx.scale), (qkv,), g)
-        return gq, None
+        # q, k, v as three leaves: their gradients land in one preallocated [3, B, H, N, hd] instead of
+        # going through three zero-filled select-backward tensors and two adds
+        grads = _vjp(lambda q, k, v: _attention_torch(q, k, v, ctx.scale), (qkv[0], qkv[1], qkv[2]), g)
+        out = torch.empty_like(qkv)
+        for i in range(3):
+            out[i].copy_(grads[i])
+        return out, None
 
 
 def _embed_torch(img, weight, bias, cls, pos, patch):

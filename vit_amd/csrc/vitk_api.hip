@@ -289,4 +289,23 @@ int vitk_target_rank(const float* logits, const int64_t* target, int* rank, int 
                     "vitk_target_rank");
 }
 
+int vitk_layernorm_backward(const float* x, int64_t x_row_stride, const float* gamma, const void* g, int g_dtype,
+                            float* dx, float* dgamma, float* dbeta, float* partials, int partial_rows, int rows,
+                            int D, float eps, void* stream) {
+    if (!x || !gamma || !g || !dx || !dgamma || !dbeta || !partials)
+        return fail(VITK_ERR_INVALID, "vitk_layernorm_backward: null pointer");
+    if (rows <= 0 || partial_rows <= 0)
+        return fail(VITK_ERR_INVALID, "vitk_layernorm_backward: rows=%d partial_rows=%d", rows, partial_rows);
+    if (g_dtype != VITK_F32 && g_dtype != VITK_BF16)
+        return fail(VITK_ERR_UNSUPPORTED, "vitk_layernorm_backward: g_dtype=%d", g_dtype);
+    if (D % 256 != 0 || D < 256 || D > 1280)
+        return fail(VITK_ERR_UNSUPPORTED, "vitk_layernorm_backward: D=%d (supported: 256..1280 in steps of 256)", D);
+    if (!aligned16(x) || !aligned16(gamma) || !aligned16(g) || !aligned16(dx) || !aligned16(partials) ||
+        x_row_stride % 4 != 0 || x_row_stride < D)
+        return fail(VITK_ERR_INVALID, "vitk_layernorm_backward: misaligned pointer or row stride");
+    return launched(launch_layernorm_backward(x, x_row_stride, gamma, g, g_dtype == VITK_BF16, dx, dgamma, dbeta, partials,
+                                              partial_rows, rows, D, eps, reinterpret_cast<hipStream_t>(stream)),
+                    "vitk_layernorm_backward");
+}
+
 }  // extern "C"

@@ -300,3 +300,30 @@ def target_rank(logits, target, out=None):
         _lib.check(L.vitk_target_rank(_ptr(logits), _ptr(target), _ptr(out), logits.shape[0], logits.shape[1],
                                       _stream()), L)
     return out
+
+
+_ln_partials = {}
+
+
+def layernorm_backward(x, gamma, g, eps):
+    """(dx f32 [rows, D], dgamma f32 [D], dbeta f32 [D]) of y = LayerNorm(x) for the output gradient g
+    (bf16 or f32 [rows, D]); x f32 [rows, D] contiguous."""
+    L = _lib.load()
+    _chk(x, torch.float32, "x")
+    _chk(gamma, torch.float32, "gamma")
+    _chk(g, g.dtype, "g")
+    if g.dtype not in (torch.bfloat16, torch.float32) or g.shape != x.shape or x.dim() != 2:
+        raise _lib.VitkError(f"layernorm_backward: x {tuple(x.shape)} {x.dtype}, g {tuple(g.shape)} {g.dtype}")
+    rows, D = x.shape
+    key = (x.device, D)
+    part = _ln_partials.get(key)
+    if part is None:
+        part = _ln_partials[key] = torch.empty(1024, 2, D, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(D, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(D, dtype=torch.float32, device=x.device)
+    gd = _lib.VITK_BF16 if g.dtype == torch.bfloat16 else _lib.VITK_F32
+    with _span("layernorm_backward"):
+        _lib.check(L.vitk_layernorm_backward(_ptr(x), D, _ptr(gamma), _ptr(g), gd, _ptr(dx), _ptr(dgamma), _ptr(dbeta),
+                                             _ptr(part), part.shape[0], rows, D, float(eps), _stream()), L)
+    return dx, dgamma, dbeta

@@ -135,3 +135,22 @@ def test_gpu_layernorm_backward_kernel(rows, D, gdt):
     assert (db.cpu().double() - wb).abs().max() <= 2e-5 * scale
     dx2, dg2, db2 = ops.layernorm_backward(x.cuda(), gamma.cuda(), g.cuda(), 1e-6)
     assert torch.equal(dg, dg2) and torch.equal(db, db2) and torch.equal(dx, dx2)      # fixed summation order
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,M,N", [(64, 256, 256), (256, 256, 512), (4096, 768, 256), (12608, 768, 768),
+                                   (50432, 3072, 768), (50432, 768, 3072), (50432, 2304, 768), (50432, 768, 768)])
+def test_gpu_weight_gradient_gemm(R, M, N):
+    """vitk_gemm_tn (dW = dY^T X with the k range split over workgroups) against an fp64 product of the same
+    bf16 operands; reproducible run to run."""
+    from vit_amd import ops
+    gen = torch.Generator().manual_seed(R + M + N)
+    g = (torch.randn(R, M, generator=gen) * 0.5).to(torch.bfloat16)
+    x = torch.randn(R, N, generator=gen).to(torch.bfloat16)
+    gd, xd = g.cuda(), x.cuda()
+    want = (gd.double().t() @ xd.double()).cpu()
+    got = ops.gemm_tn(gd, xd)
+    err = (got.cpu().double() - want).abs().max()
+    assert err <= 1e-5 * (R ** 0.5) * 4 + 1e-6, f"max abs error {err:.3e}"
+    assert torch.equal(got, ops.gemm_tn(gd, xd))
+    assert not ops.gemm_tn_supported(1000, 768, R) and not ops.gemm_tn_supported(768, 768, 100)

@@ -5,7 +5,8 @@ target); loss.backward(); clip_grad_norm_; optimizer.step()`).  Here every forwa
 kernel; each Function keeps what its backward needs and computes the gradients with torch operations on
 the GPU (library GEMMs, aten backward ops), recomputing cheap intermediates instead of storing them.
 Gradients arrive at the module's ordinary fp32 Parameters, so optimizers, `clip_grad_norm_` and
-DistributedDataParallel work unchanged.  Hand-written backward kernels so far: LayerNorm.
+DistributedDataParallel work unchanged.  Hand-written backward kernels so far: LayerNorm and the weight-gradient
+GEMM (dW = dY^T X).
 
 cd = compute dtype of the GEMM operands: torch.bfloat16, or torch.float32 in the fp32 mode.
 """
@@ -45,7 +46,10 @@ class LayerNormFn(torch.autograd.Function):
 def _linear_backward(g_pre, a, w_cd, weight, bias):
     """g_pre [rows, out] in cd -> (grad a [rows, in] in cd, grad weight f32, grad bias f32)."""
     ga = g_pre @ w_cd
-    gw = (g_pre.t() @ a).to(weight.dtype)
+    if g_pre.dtype == torch.bfloat16 and ops.gemm_tn_supported(g_pre.shape[1], a.shape[1], a.shape[0]):
+        gw = ops.gemm_tn(g_pre.contiguous(), a.contiguous()).to(weight.dtype)       # HIP: split-k dY^T X, f32 out
+    else:
+        gw = (g_pre.t() @ a).to(weight.dtype)
     gb = None if bias is None else g_pre.sum(0, dtype=torch.float32).to(bias.dtype)
     return ga, gw, gb
 

@@ -1,0 +1,187 @@
+// Weight-gradient GEMM of the training step (gfx950 / CDNA4):
+//
+//   C[m][n] = sum_k G[k][m] * X[k][n]        G bf16 [R, M], X bf16 [R, N] (row-major: k is the slow index)
+//
+// i.e. dW = dY^T X for a Linear layer (dY = G: rows x out, X: rows x in).  R = batch * tokens is ~50 k while
+// M x N is at most 3072 x 768, so the 256 x 256 output tiles alone would occupy a tenth of the chip: the k
+// range is split over S workgroups per tile, each writes an f32 partial tile, and a second kernel adds the
+// S partials in a fixed order (reproducible; no atomics).
+//
+// Both operands are k-major in memory, the wrong way round for an MFMA fragment (8 consecutive k per
+// lane).  A K tile (64 rows of k) of each operand goes to LDS as it lies in memory (LDS-DMA, 512-byte
+// rows of 256 m or n), and the fragments come out through ds_read_b64_tr_b16, which hands each lane of a
+// 16-lane group the 4 k values of one column out of a 4 x 16 block: two such reads per operand
+// fragment of v_mfma_f32_16x16x32_bf16.  32-byte unit u (16 columns = one MFMA tile) of row k is stored
+// at unit u ^ f(k), f(k) = (k & 3) | (((k >> 3) & 1) << 2): the 8 rows that 32 lanes of a transposed
+// read touch then sit in 8 different bank groups.  LDS-DMA writes linearly, so the XOR is applied to
+// each lane's source column.
+//
+// 8 waves, wave (wm, wn) owns 128 m x 64 n of the tile (8 x 4 MFMA tiles, 128 accumulator registers).
+// Two LDS stages; per K tile: wait for this wave's DMA, barrier, issue the next K tile's DMA into the other
+// stage, then for each of the two k-steps 24 transposed reads and 32 MFMA.  The transposed reads are
+// inline asm with their own lgkmcnt waits: issued through the builtin, the compiler would put
+// s_waitcnt vmcnt(0) in front of them while the next tile's LDS-DMA is in flight.
+#include <type_traits>
+
+#include "gemm_plan.h"
+
+namespace vitk {
+
+constexpr int kTnStage = 64 * 512;            // one operand K tile: 64 k-rows x 256 columns bf16
+constexpr int kTnLds = 4 * kTnStage;          // [G stage 0][G stage 1][X stage 0][X stage 1]
+
+__global__ __launch_bounds__(512, 2) void gemm_tn_partial(const bf16_t* __restrict__ G, const bf16_t* __restrict__ X,
+                                                          float* __restrict__ part, int M, int N, int ldg, int ldx,
+                                                          int ktiles_total, int splits) {
+    __shared__ __attribute__((aligned(1024))) char smem[kTnLds];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = N >> 8, tiles_m = M >> 8;
+    int idx = blockIdx.x;
+    const int tn = idx % tiles_n;
+    idx /= tiles_n;
+    const int tm = idx % tiles_m;
+    const int split = idx / tiles_m;
+    const int kt0 = (int)((long)split * ktiles_total / splits), kt1 = (int)((long)(split + 1) * ktiles_total / splits);
+    const int ktiles = kt1 - kt0;
+    const int m0 = tm << 8, n0 = tn << 8;
+
+    // ---- LDS-DMA: instruction t (0..31) of an operand tile carries k-rows 2t, 2t+1; wave w issues t = 4w..4w+3
+    uint32_t g_off[4], x_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = 2 * (wave * 4 + i) + (lane >> 5);
+        const int p = lane & 31;
+        const int f = (k & 3) | (((k >> 3) & 1) << 2);
+        const int col = (((p >> 1) ^ f) << 4) + (p & 1) * 8;
+        g_off[i] = ((uint32_t)k * ldg + m0 + col) * 2u;
+        x_off[i] = ((uint32_t)k * ldx + n0 + col) * 2u;
+    }
+    const char* g_base = reinterpret_cast<const char*>(G) + (size_t)kt0 * 64 * ldg * 2;
+    const char* x_base = reinterpret_cast<const char*>(X) + (size_t)kt0 * 64 * ldx * 2;
+    const size_t g_step = (size_t)64 * ldg * 2, x_step = (size_t)64 * ldx * 2;
+    auto issue = [&](int stage, int kt) {
+        const char* gs = g_base + kt * g_step;
+        const char* xs = x_base + kt * x_step;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            char* dg = smem + stage * kTnStage + (wave * 4 + i) * 1024;
+            char* dx = smem + 2 * kTnStage + stage * kTnStage + (wave * 4 + i) * 1024;
+            __builtin_amdgcn_global_load_lds((gbl_void*)(gs + g_off[i]), (lds_void*)dg, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(xs + x_off[i]), (lds_void*)dx, 16, 0, 0);
+        }
+    };
+
+    // ---- fragment addresses: lane (q = lane / 16: the 8 k of a k-step, tq: row within 4, tp: 8-byte piece)
+    const int q = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+    const int fl = tq | ((q & 1) << 2);                        // f(k) of every row this lane addresses
+    const int wm = wave >> 2, wn = wave & 3;                   // 2 x 4 waves: 128 m x 64 n each
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
+    const uint32_t row_b = (uint32_t)((8 * q + tq) * 512 + tp * 8);
+    uint32_t ga[8], xa[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ga[j] = lds0 + row_b + (uint32_t)(((wm * 8 + j) ^ fl) << 5);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xa[j] = lds0 + 2 * kTnStage + row_b + (uint32_t)(((wn * 4 + j) ^ fl) << 5);
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // one k-step (32 k) of the K tile in `stage`: fragments = [k 8q..8q+3 | k 8q+4..8q+7] of the lane's column
+    auto k_step = [&](auto stage_c, auto kk_c) {
+        constexpr int off = decltype(stage_c)::value * kTnStage + decltype(kk_c)::value * 32 * 512;
+        bf16x4 gl[8], gh[8], xl[4], xh[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xl[j]) : "v"(xa[j]), "n"(off));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xh[j]) : "v"(xa[j]), "n"(off + 4 * 512));
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(gl[j]) : "v"(ga[j]), "n"(off));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(gh[j]) : "v"(ga[j]), "n"(off + 4 * 512));
+        }
+        // the wait carries the fragment registers as operands, so the MFMAs below cannot move above it
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(xl[0]), "+v"(xl[1]), "+v"(xl[2]), "+v"(xl[3]), "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]));
+        asm volatile("" : "+v"(gl[0]), "+v"(gl[1]), "+v"(gl[2]), "+v"(gl[3]), "+v"(gl[4]), "+v"(gl[5]), "+v"(gl[6]), "+v"(gl[7]));
+        asm volatile("" : "+v"(gh[0]), "+v"(gh[1]), "+v"(gh[2]), "+v"(gh[3]), "+v"(gh[4]), "+v"(gh[5]), "+v"(gh[6]), "+v"(gh[7]));
+        bf16x8 xf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xf[i] = __builtin_shufflevector(xl[i], xh[i], 0, 1, 2, 3, 4, 5, 6, 7);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bf16x8 gf = __builtin_shufflevector(gl[j], gh[j], 0, 1, 2, 3, 4, 5, 6, 7);
+            // MFMA row index = n, column index = m: a lane ends up with 4 consecutive n of one row m
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], gf, acc[j][i], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    auto k_tile = [&](auto stage_c, int kt) {
+        constexpr int stage = decltype(stage_c)::value;
+        __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): this wave's pieces of K tile kt have landed
+        __builtin_amdgcn_s_barrier();                          // everyone's have; everyone is done with the other stage
+        if (kt + 1 < ktiles) issue(stage ^ 1, kt + 1);
+        k_step(stage_c, C0{});
+        k_step(stage_c, C1{});
+    };
+
+    if (ktiles > 0) issue(0, 0);
+    for (int kt = 0; kt < ktiles; kt += 2) {
+        k_tile(C0{}, kt);
+        if (kt + 1 < ktiles) k_tile(C1{}, kt + 1);
+    }
+
+    // ---- partial tile: acc[j][i][r] = C[m0 + 128 wm + 16 j + lane % 16][n0 + 64 wn + 16 i + 4 (lane / 16) + r]
+    float* out = part + ((size_t)split * M + m0 + wm * 128 + (lane & 15)) * N + n0 + wn * 64 + 4 * (lane >> 4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(out + (size_t)j * 16 * N + i * 16) = acc[j][i];
+}
+
+// C = sum over the S partials, in split order
+__global__ __launch_bounds__(256) void gemm_tn_reduce(const float* __restrict__ part, float* __restrict__ C, size_t mn4,
+                                                      int splits) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < mn4; i += stride) {
+        f32x4 a = reinterpret_cast<const f32x4*>(part)[i];
+        for (int s = 1; s < splits; ++s) a = a + reinterpret_cast<const f32x4*>(part)[(size_t)s * mn4 + i];
+        reinterpret_cast<f32x4*>(C)[i] = a;
+    }
+}
+
+// number of k splits: one workgroup per CU where the k range allows (at least 4 K tiles per split)
+int gemm_tn_splits(int M, int N, int R) {
+    const int tiles = (M >> 8) * (N >> 8), ktiles = R / 64;
+    if (tiles <= 0 || ktiles <= 0) return 0;
+    int s = num_cus() / tiles;
+    if (s < 1) s = 1;
+    if (s > ktiles / 4) s = ktiles / 4 > 0 ? ktiles / 4 : 1;
+    return s;
+}
+
+hipError_t launch_gemm_tn(const void* G, const void* X, float* C, float* part, int M, int N, int R, int ldg, int ldx,
+                          hipStream_t s) {
+    const int splits = gemm_tn_splits(M, N, R);
+    if (splits <= 0) return hipErrorInvalidValue;
+    const int grid = (M >> 8) * (N >> 8) * splits;
+    hipLaunchKernelGGL(gemm_tn_partial, dim3(grid), dim3(512), 0, s, reinterpret_cast<const bf16_t*>(G),
+                       reinterpret_cast<const bf16_t*>(X), splits == 1 ? C : part, M, N, ldg, ldx, R / 64, splits);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || splits == 1) return e;
+    const size_t mn4 = (size_t)M * N / 4;
+    size_t blocks = (mn4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gemm_tn_reduce, dim3((unsigned)blocks), dim3(256), 0, s, part, C, mn4, splits);
+    return hipGetLastError();
+}
+
+}  // namespace vitk

@@ -308,4 +308,25 @@ int vitk_layernorm_backward(const float* x, int64_t x_row_stride, const float* g
                     "vitk_layernorm_backward");
 }
 
+int64_t vitk_gemm_tn_workspace(int M, int N, int R) {
+    if (M <= 0 || N <= 0 || R <= 0 || M % 256 || N % 256 || R % 64) return -1;
+    const int splits = gemm_tn_splits(M, N, R);
+    return splits <= 1 ? 0 : (int64_t)splits * M * N;
+}
+
+int vitk_gemm_tn(const void* G, const void* X, float* C, float* workspace, int64_t workspace_floats, int M, int N,
+                 int R, void* stream) {
+    if (!G || !X || !C) return fail(VITK_ERR_INVALID, "vitk_gemm_tn: null pointer");
+    if (M <= 0 || N <= 0 || R <= 0 || M % 256 || N % 256 || R % 64)
+        return fail(VITK_ERR_UNSUPPORTED, "vitk_gemm_tn: M=%d N=%d R=%d (M, N multiples of 256, R of 64)", M, N, R);
+    if ((int64_t)R * (M > N ? M : N) * 2 >= ((int64_t)1 << 32))
+        return fail(VITK_ERR_UNSUPPORTED, "vitk_gemm_tn: operand of 4 GiB or more");
+    const int64_t need = vitk_gemm_tn_workspace(M, N, R);
+    if (need > 0 && (!workspace || workspace_floats < need))
+        return fail(VITK_ERR_INVALID, "vitk_gemm_tn: workspace of %lld floats needed", (long long)need);
+    if (!aligned16(G) || !aligned16(X) || !aligned16(C) || (workspace && !aligned16(workspace)))
+        return fail(VITK_ERR_INVALID, "vitk_gemm_tn: pointers must be 16-byte aligned");
+    return launched(launch_gemm_tn(G, X, C, workspace, M, N, R, M, N, reinterpret_cast<hipStream_t>(stream)), "vitk_gemm_tn");
+}
+
 }  // extern "C"

@@ -45,6 +45,9 @@ hipError_t launch_im2col(const void* img, void* cols, int batch, int img_h, int 
 hipError_t launch_layernorm_backward(const float* x, int64_t x_row_stride, const float* gamma, const void* g,
                                      bool g_bf16, float* dx, float* dgamma, float* dbeta, float* partials,
                                      int partial_rows, int rows, int D, float eps, hipStream_t s);
+int gemm_tn_splits(int M, int N, int R);
+hipError_t launch_gemm_tn(const void* G, const void* X, float* C, float* part, int M, int N, int R, int ldg, int ldx,
+                          hipStream_t s);
 hipError_t launch_normalize_u8(const void* in, void* out, int64_t n, int64_t plane, const float* mean,
                                const float* std, bool out_bf16, hipStream_t s);
 hipError_t launch_target_rank(const float* logits, const int64_t* target, int* rank, int rows, int classes,

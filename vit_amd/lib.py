@@ -36,10 +36,12 @@ SIGNATURES = {
     "vitk_pos_embed_scale": [_p, _p, _i, _i, _i, _p],
     "vitk_normalize_u8": [_p, _p, _i, _i, _i, _p, _p, _i, _p],
     "vitk_target_rank": [_p, _p, _p, _i, _i, _p],
+    "vitk_gemm_tn": [_p, _p, _p, _p, _i64, _i, _i, _i, _p],
     "vitk_layernorm_backward": [_p, _i64, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _f, _p],
 }
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_TANH = 0, 1, 2, 3      # vitk_gemm_f32 epilogues (include/vitk.h)
-EXPORTS = sorted(list(SIGNATURES) + ["vitk_version", "vitk_last_error", "vitk_set_debug_variant"])
+EXPORTS = sorted(list(SIGNATURES) + ["vitk_version", "vitk_last_error", "vitk_set_debug_variant",
+                                    "vitk_gemm_tn_workspace"])
 
 _lib = None
 
@@ -64,6 +66,8 @@ def load():
     lib.vitk_last_error.argtypes = []
     lib.vitk_set_debug_variant.restype = None
     lib.vitk_set_debug_variant.argtypes = [_i, _i]
+    lib.vitk_gemm_tn_workspace.restype = _i64
+    lib.vitk_gemm_tn_workspace.argtypes = [_i, _i, _i]
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = _i

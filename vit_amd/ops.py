@@ -327,3 +327,34 @@ def layernorm_backward(x, gamma, g, eps):
         _lib.check(L.vitk_layernorm_backward(_ptr(x), D, _ptr(gamma), _ptr(g), gd, _ptr(dx), _ptr(dgamma), _ptr(dbeta),
                                              _ptr(part), part.shape[0], rows, D, float(eps), _stream()), L)
     return dx, dgamma, dbeta
+
+
+_tn_workspace = {}
+
+
+def gemm_tn_supported(M, N, R):
+    return _lib.load().vitk_gemm_tn_workspace(M, N, R) >= 0
+
+
+def gemm_tn(g, x, out=None):
+    """out f32 [M, N] = g^T x for g bf16 [R, M], x bf16 [R, N] (the weight gradient of a Linear layer)."""
+    L = _lib.load()
+    _chk(g, torch.bfloat16, "g")
+    _chk(x, torch.bfloat16, "x")
+    if g.dim() != 2 or x.dim() != 2 or g.shape[0] != x.shape[0]:
+        raise _lib.VitkError(f"gemm_tn: g {tuple(g.shape)}, x {tuple(x.shape)}")
+    R, M = g.shape
+    N = x.shape[1]
+    need = L.vitk_gemm_tn_workspace(M, N, R)
+    if need < 0:
+        raise _lib.VitkError(f"gemm_tn: unsupported shape M={M} N={N} R={R} (M, N multiples of 256, R of 64)")
+    ws = _tn_workspace.get(g.device)
+    if need > 0 and (ws is None or ws.numel() < need):
+        ws = _tn_workspace[g.device] = torch.empty(need, dtype=torch.float32, device=g.device)
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=g.device)
+    _chk(out, torch.float32, "out")
+    with _span("gemm_tn"):
+        _lib.check(L.vitk_gemm_tn(_ptr(g), _ptr(x), _ptr(out), _ptr(ws) if need > 0 else None, ws.numel() if need > 0 else 0,
+                                  M, N, R, _stream()), L)
+    return out

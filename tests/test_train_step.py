@@ -135,6 +135,9 @@ def test_gpu_layernorm_backward_kernel(rows, D, gdt):
     assert (db.cpu().double() - wb).abs().max() <= 2e-5 * scale
     dx2, dg2, db2 = ops.layernorm_backward(x.cuda(), gamma.cuda(), g.cuda(), 1e-6)
     assert torch.equal(dg, dg2) and torch.equal(db, db2) and torch.equal(dx, dx2)      # fixed summation order
+    skip = torch.randn(rows, D, generator=gen)
+    dx3, _, _ = ops.layernorm_backward(x.cuda(), gamma.cuda(), g.cuda(), 1e-6, add=skip.cuda())
+    assert torch.allclose(dx3.cpu().double(), wx + skip.double(), rtol=1e-4, atol=2e-5)  # residual-branch gradient added
 
 
 @pytest.mark.gpu

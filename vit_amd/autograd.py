@@ -26,7 +26,11 @@ def _vjp(fn, inputs, grad_out):
 
 
 class LayerNormFn(torch.autograd.Function):
-    """y = LayerNorm(x) in cd; x f32 [rows, D] (models/transformer.py:68,73,98)."""
+    """(y, x) with y = LayerNorm(x) in cd; x f32 [rows, D] (models/transformer.py:68,73,98).
+
+    The second output is x again, for the residual branch that skips the block's body
+    (models/transformer.py:72,76): whatever gradient reaches it is added to the LayerNorm's own input gradient
+    inside the backward kernel, instead of by autograd's separate add over both tensors."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, eps, cd):
@@ -34,12 +38,16 @@ class LayerNormFn(torch.autograd.Function):
         ops.layernorm(x, weight.detach(), bias.detach(), eps, out)
         ctx.save_for_backward(x, weight, bias)
         ctx.eps = eps
-        return out
+        ctx.set_materialize_grads(False)
+        return out, x.view_as(x)
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_skip):
         x, weight, bias = ctx.saved_tensors
-        gx, gw, gb = ops.layernorm_backward(x, weight.detach(), g.contiguous(), ctx.eps)
+        if g is None:                                                     # only the skip output was used
+            return g_skip, None, None, None, None
+        add = None if g_skip is None else g_skip.contiguous()
+        gx, gw, gb = ops.layernorm_backward(x, weight.detach(), g.contiguous(), ctx.eps, add=add)
         return gx, gw.to(weight.dtype), gb.to(bias.dtype), None, None
 
 
@@ -156,10 +164,12 @@ class AttentionFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (qkv,) = ctx.saved_tensors
-        # q, k, v as three leaves: their gradients land in one preallocated [3, B, H, N, hd] instead of
-        # going through three zero-filled select-backward tensors and two adds
+        # q, k, v as three leaves; their gradients are written into one buffer laid out [B, N, 3, H, hd],
+        # i.e. already the [rows, 3 D] matrix the projection's backward GEMMs want, and handed on as a
+        # [3, B, H, N, hd] view of it (no zero-filled select-backward tensors, no adds, no permute copy)
+        _, B, H, N, hd = qkv.shape
         grads = _vjp(lambda q, k, v: _attention_torch(q, k, v, ctx.scale), (qkv[0], qkv[1], qkv[2]), g)
-        out = torch.empty_like(qkv)
+        out = torch.empty(B, N, 3, H, hd, dtype=qkv.dtype, device=qkv.device).permute(2, 0, 3, 1, 4)
         for i in range(3):
             out[i].copy_(grads[i])
         return out, None
@@ -226,16 +236,16 @@ def forward_train(model, x):
     for i, blk in enumerate(model.encoder.blocks):
         p = f"b{i}."
         att, mlp = blk.attention, blk.mlp
-        y = LayerNormFn.apply(x2, blk.norm1.weight, blk.norm1.bias, float(blk.norm1.eps), cd)
+        y, x2 = LayerNormFn.apply(x2, blk.norm1.weight, blk.norm1.bias, float(blk.norm1.eps), cd)
         qkv = QkvFn.apply(y, att.in_proj.weight, att.in_proj.bias, w[p + "qkv.w"], B, N, H, hd)
         ctxt = AttentionFn.apply(qkv, att.scaling)
         x2 = LinearFn.apply(ctxt.view(B * N, D), att.out_proj.weight, att.out_proj.bias, w[p + "out.w"], "resid", x2)
-        y = LayerNormFn.apply(x2, blk.norm2.weight, blk.norm2.bias, float(blk.norm2.eps), cd)
+        y, x2 = LayerNormFn.apply(x2, blk.norm2.weight, blk.norm2.bias, float(blk.norm2.eps), cd)
         h = LinearFn.apply(y, mlp.fc1.weight, mlp.fc1.bias, w[p + "fc1.w"], "gelu", None)
         x2 = LinearFn.apply(h, mlp.fc2.weight, mlp.fc2.bias, w[p + "fc2.w"], "resid", x2)
     cls_rows = x2.view(B, N, D)[:, 0].contiguous()                         # the reference keeps token 0 (transformer.py:99)
     norm = model.encoder.norm
-    feat = LayerNormFn.apply(cls_rows, norm.weight, norm.bias, float(norm.eps), cd)
+    feat, _ = LayerNormFn.apply(cls_rows, norm.weight, norm.bias, float(norm.eps), cd)
     if "pre.w" in w:
         feat = LinearFn.apply(feat, model.pre_logits.weight, model.pre_logits.bias, w["pre.w"], "tanh", None)
     logits = LinearFn.apply(feat, model.head.weight, model.head.bias, w["head.w"], "logits", None)

@@ -305,13 +305,16 @@ def target_rank(logits, target, out=None):
 _ln_partials = {}
 
 
-def layernorm_backward(x, gamma, g, eps):
+def layernorm_backward(x, gamma, g, eps, add=None):
     """(dx f32 [rows, D], dgamma f32 [D], dbeta f32 [D]) of y = LayerNorm(x) for the output gradient g
-    (bf16 or f32 [rows, D]); x f32 [rows, D] contiguous."""
+    (bf16 or f32 [rows, D]); x f32 [rows, D] contiguous; add (f32 [rows, D], optional) is added to dx."""
     L = _lib.load()
     _chk(x, torch.float32, "x")
     _chk(gamma, torch.float32, "gamma")
     _chk(g, g.dtype, "g")
+    _chk(add, torch.float32, "add")
+    if add is not None and add.shape != x.shape:
+        raise _lib.VitkError(f"layernorm_backward: add {tuple(add.shape)} vs x {tuple(x.shape)}")
     if g.dtype not in (torch.bfloat16, torch.float32) or g.shape != x.shape or x.dim() != 2:
         raise _lib.VitkError(f"layernorm_backward: x {tuple(x.shape)} {x.dtype}, g {tuple(g.shape)} {g.dtype}")
     rows, D = x.shape
@@ -324,7 +327,7 @@ def layernorm_backward(x, gamma, g, eps):
     dbeta = torch.empty(D, dtype=torch.float32, device=x.device)
     gd = _lib.VITK_BF16 if g.dtype == torch.bfloat16 else _lib.VITK_F32
     with _span("layernorm_backward"):
-        _lib.check(L.vitk_layernorm_backward(_ptr(x), D, _ptr(gamma), _ptr(g), gd, _ptr(dx), _ptr(dgamma), _ptr(dbeta),
+        _lib.check(L.vitk_layernorm_backward(_ptr(x), D, _ptr(gamma), _ptr(g), gd, _ptr(add), _ptr(dx), _ptr(dgamma), _ptr(dbeta),
                                              _ptr(part), part.shape[0], rows, D, float(eps), _stream()), L)
     return dx, dgamma, dbeta
 

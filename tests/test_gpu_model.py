@@ -109,8 +109,8 @@ def test_weight_update_invalidates_cache_and_extra_shapes():
     with pytest.raises(vit_amd.VitkError):
         with torch.no_grad():
             m(torch.zeros(1, 3, 384, 384, device=DEV))         # token count does not match pos_embed
-    with pytest.raises(vit_amd.VitkError):
-        m(xd)                                                   # grad enabled: forward-only path
+    y2 = m(xd)                                                  # grad enabled: the same kernels under autograd
+    assert y2.requires_grad and torch.equal(y2.detach(), y1)
 
 
 def test_unsupported_head_dim_is_rejected_not_faked():

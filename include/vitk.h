@@ -195,6 +195,19 @@ int64_t vitk_gemm_tn_workspace(int M, int N, int R);
 int vitk_gemm_tn(const void* G, const void* X, float* C, float* workspace, int64_t workspace_floats, int M, int N,
                  int R, void* stream);
 
+/* vitk_attention for the training step: additionally writes lse f32 [batch, heads, ntok], the log2 of each query
+ * row's softmax denominator in units of scores * scale * log2(e), which vitk_attention_backward needs. */
+int vitk_attention_lse(const void* q, const void* k, const void* v, void* ctx, float* lse, int batch, int heads,
+                       int ntok, int hd, float scale, void* stream);
+
+/* Backward of vitk_attention (the reference differentiates models/transformer.py:43-46 by autograd): from q, k, v
+ * (bf16 [batch, heads, ntok, hd]), the forward's ctx and lse, and dctx (bf16 [batch, ntok, heads*hd]) to
+ * dqkv bf16 [batch, ntok, 3, heads, hd] = the gradient of the fused projection's output as a [rows, 3 D] matrix.
+ * dbuf: caller's scratch, f32 [batch, heads, ntok].  hd = 64, ntok <= 576. */
+int vitk_attention_backward(const void* q, const void* k, const void* v, const void* ctx, const void* dctx,
+                            const float* lse, float* dbuf, void* dqkv, int batch, int heads, int ntok, int hd,
+                            float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

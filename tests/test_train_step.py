@@ -157,3 +157,36 @@ def test_gpu_weight_gradient_gemm(R, M, N):
     assert err <= 1e-5 * (R ** 0.5) * 4 + 1e-6, f"max abs error {err:.3e}"
     assert torch.equal(got, ops.gemm_tn(gd, xd))
     assert not ops.gemm_tn_supported(1000, 768, R) and not ops.gemm_tn_supported(768, 768, 100)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,N", [(2, 3, 197), (1, 2, 32), (1, 2, 33), (2, 2, 64), (1, 4, 257), (1, 1, 576), (3, 12, 197)])
+def test_gpu_attention_backward_kernel(B, H, N):
+    """vitk_attention_lse + vitk_attention_backward against torch autograd of softmax(q k^T s) v in fp64 on the
+    same bf16 q, k, v and output gradient."""
+    from vit_amd import ops
+    hd, scale = 64, 64 ** -0.5
+    gen = torch.Generator().manual_seed(B * 1000 + N)
+    qkv = torch.randn(3, B, H, N, hd, generator=gen).to(torch.bfloat16)
+    dctx = torch.randn(B, N, H * hd, generator=gen).to(torch.bfloat16)
+    q, k, v = (qkv[i].double().requires_grad_(True) for i in range(3))
+    o = ((q @ k.transpose(-2, -1)) * scale).softmax(-1) @ v
+    o2 = o.transpose(1, 2).reshape(B, N, H * hd)
+    gq, gk, gv = torch.autograd.grad(o2, (q, k, v), dctx.double())
+    want = torch.stack((gq, gk, gv)).permute(1, 3, 0, 2, 4)                 # [B, N, 3, H, hd]
+    qd = qkv.cuda()
+    ctx = torch.empty(B, N, H * hd, dtype=torch.bfloat16, device="cuda")
+    lse = ops.attention_lse(qd, ctx, scale)
+    s2 = (q.detach() @ k.detach().transpose(-2, -1)) * scale * 1.4426950408889634
+    want_lse = torch.logsumexp(s2 * 0.6931471805599453, -1) * 1.4426950408889634
+    assert torch.allclose(lse.cpu().double(), want_lse, atol=2e-3)
+    assert torch.allclose(ctx.float().cpu().double(), o2.detach(), rtol=2e-2, atol=6e-3)
+    got = ops.attention_backward(qd, ctx, dctx.cuda(), lse, scale)
+    assert got.shape == (B, N, 3, H, hd)
+    err = (got.float().cpu().double() - want).abs().max()
+    ref = want.abs().max()
+    assert err <= 2e-2 * ref + 1e-3, f"max abs error {err:.3e} (gradient magnitude {ref:.3e})"
+    for w in range(3):
+        a, bb = got[:, :, w].float().cpu().double().reshape(-1), want[:, :, w].reshape(-1)
+        cos = float(a @ bb / (a.norm() * bb.norm()))
+        assert cos > 0.9995, (w, cos)

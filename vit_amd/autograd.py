@@ -5,8 +5,8 @@ target); loss.backward(); clip_grad_norm_; optimizer.step()`).  Here every forwa
 kernel; each Function keeps what its backward needs and computes the gradients with torch operations on
 the GPU (library GEMMs, aten backward ops), recomputing cheap intermediates instead of storing them.
 Gradients arrive at the module's ordinary fp32 Parameters, so optimizers, `clip_grad_norm_` and
-DistributedDataParallel work unchanged.  Hand-written backward kernels so far: LayerNorm and the weight-gradient
-GEMM (dW = dY^T X).
+DistributedDataParallel work unchanged.  Hand-written backward kernels so far: LayerNorm, the weight-gradient
+GEMM (dW = dY^T X) and attention.
 
 cd = compute dtype of the GEMM operands: torch.bfloat16, or torch.float32 in the fp32 mode.
 """
@@ -147,32 +147,39 @@ def _attention_torch(q, k, v, scale):
 
 
 class AttentionFn(torch.autograd.Function):
-    """ctx [B, N, H*hd] = softmax(q k^T scale) v, heads concatenated (models/transformer.py:43-46)."""
+    """ctx [B, N, H*hd] = softmax(q k^T scale) v, heads concatenated (models/transformer.py:43-46).
+
+    bf16, head_dim 64, N <= 576: the forward also keeps each row's log-sum-exp and the backward is the HIP
+    kernel pair of attention_bwd.hip.  Otherwise the gradients come from recomputing with torch."""
 
     @staticmethod
     def forward(ctx, qkv, scale):
         _, B, H, N, hd = qkv.shape
         out = torch.empty(B, N, H * hd, dtype=qkv.dtype, device=qkv.device)
+        lse = None
         if qkv.dtype == torch.float32:
             ops.attention_f32(qkv, out, scale)
+        elif ops.attention_backward_supported(N, hd):
+            lse = ops.attention_lse(qkv, out, scale)
         else:
             ops.attention(qkv, out, scale)
-        ctx.save_for_backward(qkv)
+        ctx.save_for_backward(qkv, out, lse)
         ctx.scale = scale
         return out
 
     @staticmethod
     def backward(ctx, g):
-        (qkv,) = ctx.saved_tensors
-        # q, k, v as three leaves; their gradients are written into one buffer laid out [B, N, 3, H, hd],
-        # i.e. already the [rows, 3 D] matrix the projection's backward GEMMs want, and handed on as a
-        # [3, B, H, N, hd] view of it (no zero-filled select-backward tensors, no adds, no permute copy)
+        qkv, out, lse = ctx.saved_tensors
         _, B, H, N, hd = qkv.shape
+        # gradients laid out [B, N, 3, H, hd], i.e. already the [rows, 3 D] matrix the projection's backward
+        # GEMMs want, handed on as a [3, B, H, N, hd] view of it
+        if lse is not None:
+            return ops.attention_backward(qkv, out, g.contiguous(), lse, ctx.scale).permute(2, 0, 3, 1, 4), None
         grads = _vjp(lambda q, k, v: _attention_torch(q, k, v, ctx.scale), (qkv[0], qkv[1], qkv[2]), g)
-        out = torch.empty(B, N, 3, H, hd, dtype=qkv.dtype, device=qkv.device).permute(2, 0, 3, 1, 4)
+        dqkv = torch.empty(B, N, 3, H, hd, dtype=qkv.dtype, device=qkv.device).permute(2, 0, 3, 1, 4)
         for i in range(3):
-            out[i].copy_(grads[i])
-        return out, None
+            dqkv[i].copy_(grads[i])
+        return dqkv, None
 
 
 def _embed_torch(img, weight, bias, cls, pos, patch):

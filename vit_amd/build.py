@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvitk.so")
-SOURCES = ["vitk_api.hip", "gemm.hip", "gemm_pipe.hip", "gemm_pp.hip", "attention.hip", "rowops.hip", "f32path.hip", "backward.hip", "gemm_tn.hip"]
+SOURCES = ["vitk_api.hip", "gemm.hip", "gemm_pipe.hip", "gemm_pp.hip", "attention.hip", "rowops.hip", "f32path.hip", "backward.hip", "gemm_tn.hip", "attention_bwd.hip"]
 HEADERS = [os.path.join(CSRC, "vitk_common.h"), os.path.join(CSRC, "vitk_kernels.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "gemm_plan.h"),
            os.path.join(os.path.dirname(HERE), "include", "vitk.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=fast"]

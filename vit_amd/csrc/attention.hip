@@ -29,6 +29,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
 
 constexpr float kMaskedScore = -1.0e30f;
+static float* g_attn_lse = nullptr;   // optional per-row log-sum-exp output of the launch being prepared
 static int g_attn_probe = 0;   // timing probes (debug variant bits 2..4): K/V of head 0, no key loop, no stores
 
 // VTR = true : V row-major in LDS, transposed fragments via ds_read_b64_tr_b16.
@@ -54,7 +55,8 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
                                                          const bf16_t* __restrict__ K,
                                                          const bf16_t* __restrict__ V,
                                                          bf16_t* __restrict__ O, int ntok, int heads,
-                                                         float scale_log2e, int probe, int nbh) {
+                                                         float scale_log2e, int probe, int nbh,
+                                                         float* __restrict__ lse) {
     static_assert(HD == 64 || ((HD == 96 || HD == 80) && VTR), "head_dim 64, or 80 / 96 with transposed LDS reads");
     static_assert(VTR || !STREAM, "streaming needs the transposed LDS reads");
     static_assert(!PD || (VTR && !STREAM), "the persistent variant stages whole heads by LDS-DMA");
@@ -331,6 +333,9 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
         const float l_tot = MSUM ? l_acc[0] : l_run + __shfl_xor(l_run, 32, 64);
         const float inv = 1.0f / l_tot;
         const int b = bh / heads, h = bh - b * heads;
+        // training: log2 of the row's softmax denominator in the kernel's units (scores * scale * log2 e),
+        // which is all the backward needs to rebuild the probabilities
+        if (lse && hh == 0 && qrow < ntok) lse[(size_t)bh * ntok + qrow] = m_run + __builtin_amdgcn_logf(l_tot);
         if constexpr (PD && HD == 64) {
             // Through a wave-private 32 x 128 B window, so that every store instruction writes 8 whole rows
             // of the head's 128-byte output slice instead of 8 bytes of 64 different rows.  8-byte piece
@@ -471,7 +476,7 @@ static hipError_t attn_launch(const void* q, const void* k, const void* v, void*
     hipLaunchKernelGGL((attention_fwd<HD, NW, VTR, STREAM, PD>), grid, block, lds, s,
                        reinterpret_cast<const bf16_t*>(q), reinterpret_cast<const bf16_t*>(k),
                        reinterpret_cast<const bf16_t*>(v), reinterpret_cast<bf16_t*>(out), ntok, heads,
-                       scale * 1.44269504088896340736f, g_attn_probe, nbh);
+                       scale * 1.44269504088896340736f, g_attn_probe, nbh, g_attn_lse);
     return hipGetLastError();
 }
 
@@ -480,7 +485,8 @@ static hipError_t attn_launch(const void* q, const void* k, const void* v, void*
 int attention_max_tokens(int hd) { return (hd == 64 || hd == 80 || hd == 96) ? 16384 : 0; }
 
 hipError_t launch_attention(const void* q, const void* k, const void* v, void* out, int batch, int heads,
-                            int ntok, int hd, float scale, int variant, hipStream_t s) {
+                            int ntok, int hd, float scale, int variant, hipStream_t s, float* lse) {
+    g_attn_lse = lse;
     if ((hd != 64 && hd != 80 && hd != 96) || ntok < 1) return hipErrorInvalidValue;
     const int qtiles = (ntok + 31) / 32;
     // variant: 0 = automatic (persistent workgroups with two resident K/V buffers when two heads fit in LDS,

@@ -1,0 +1,260 @@
+// Backward of the multi-head self-attention of the ViT blocks (models/transformer.py:42-46) for the
+// training step, head_dim 64, token counts whose K and V (or Q and dO) of one head fit in LDS
+// (gfx950 / CDNA4).
+//
+//   S = scale Q K^T,  P = softmax(S),  O = P V          (forward, attention.hip; it also leaves
+//                                                          L = log2 sum_k exp2(S log2 e) per query row)
+//   dP = dO V^T,  D = rowsum(dO * O),  dS = P * (dP - D)
+//   dQ = scale dS K,   dK = scale dS^T Q,   dV = P^T dO
+//
+// One kernel template, run twice per layer, one workgroup per (image, head) each time:
+//   MODE 0 (dQ):     K and V resident in LDS; a wave owns 32 query rows (Q, dO fragments in registers), walks
+//                    the keys in blocks of 32:  S^T = K Q^T,  dP^T = V dO^T  (key on the MFMA row, query on
+//                    the lane, so L and D are per-lane scalars),  dQ^T += K^T dS^T.  Also computes D for its
+//                    rows (from dO and O) and stores it for the second pass.
+//   MODE 1 (dK, dV): Q and dO resident; a wave owns 32 key rows (K, V fragments in registers), walks the
+//                    queries in blocks of 32:  S = Q K^T,  dP = dO V^T  (query on the MFMA row: L and D come
+//                    from LDS per accumulator row),  dK^T += Q^T dS,  dV^T += dO^T P.
+// In both modes the exponentiated / differentiated score block, packed to bf16, is directly the B operand of the
+// output products (the same trick as the forward's P.V), and the transposed A operands (K^T, Q^T, dO^T) come
+// from the row-major LDS image through ds_read_b64_tr_b16.  The probabilities are rebuilt as
+// exp2(S log2 e - L): no running maximum, no second softmax pass.
+//
+// LDS rows are 128 B; 16-byte chunk c of row r sits at slot c ^ swz(r), swz(r) = ((r >> 1) & 1) << 2 | ((r >> 2) & 3):
+// conflict-free both for the ds_read_b128 of 16 rows x one chunk column and for the transposed read of
+// 4 rows x 2 chunks.
+// Gradients are written in the layout [batch, ntok, 3, heads, 64]: the [rows, 3 D] matrix the input
+// projection's backward GEMMs take.
+#include <type_traits>
+
+#include "vitk_common.h"
+#include "vitk_kernels.h"
+
+namespace vitk {
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_b;
+typedef __attribute__((address_space(3))) void lds_void_b;
+typedef __attribute__((address_space(1))) const void gbl_void_b;
+
+template <int MODE, int NW>
+__global__ __launch_bounds__(NW * 64) void attention_bwd(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                         const bf16_t* __restrict__ V, const bf16_t* __restrict__ O,
+                                                         const bf16_t* __restrict__ dO, const float* __restrict__ LSE,
+                                                         float* __restrict__ Dbuf, bf16_t* __restrict__ dqkv, int ntok,
+                                                         int heads, float scale) {
+    constexpr int HD = 64, KS = 4, DB = 2, RB = 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bh = blockIdx.x;
+    const int b = bh / heads, h = bh - b * heads;
+    const int blocks = (ntok + 31) >> 5, npad = blocks * 32;
+    const float c = scale * 1.44269504088896340736f;
+    char* r1 = smem;                         // MODE 0: K, MODE 1: Q
+    char* r2 = smem + npad * RB;             // MODE 0: V, MODE 1: dO
+    float* l_lds = reinterpret_cast<float*>(smem + 2 * npad * RB);      // MODE 1: L and D of every query row
+    float* d_lds = l_lds + npad;
+
+    auto swz = [](int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); };
+    const size_t head_rows = (size_t)bh * ntok;              // first row of this head in Q / K / V
+    const size_t ctx_stride = (size_t)heads * HD;            // row stride of O / dO (heads concatenated)
+    const bf16_t* o_head = O + (size_t)b * ntok * ctx_stride + h * HD;
+    const bf16_t* do_head = dO + (size_t)b * ntok * ctx_stride + h * HD;
+
+    // ---- stage the two resident matrices: 8 rows per LDS-DMA instruction (1 KiB), rows past ntok re-read the last
+    {
+        const bf16_t* s1 = (MODE == 0 ? K : Q) + head_rows * HD;
+        const bf16_t* s2 = MODE == 0 ? V + head_rows * HD : do_head;
+        const size_t st2 = MODE == 0 ? HD : ctx_stride;
+        const int pieces = npad / 8;
+        for (int pi = wave; pi < 2 * pieces; pi += NW) {      // wave-uniform
+            const bool second = pi >= pieces;
+            const int lrow = (second ? pi - pieces : pi) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ swz(lrow);
+            const int grow = lrow < ntok ? lrow : ntok - 1;
+            const bf16_t* src = second ? s2 + (size_t)grow * st2 + chunk * 8 : s1 + (size_t)grow * HD + chunk * 8;
+            __builtin_amdgcn_global_load_lds((gbl_void_b*)src, (lds_void_b*)(smem + pi * 1024), 16, 0, 0);
+        }
+        if constexpr (MODE == 1) {
+            for (int i = tid; i < npad; i += NW * 64) {
+                l_lds[i] = i < ntok ? LSE[head_rows + i] : 1.0e30f;        // padded queries: probability 0
+                d_lds[i] = i < ntok ? Dbuf[head_rows + i] : 0.f;
+            }
+        }
+    }
+
+    const int r = lane & 31, hh = lane >> 5;
+    const int tsub = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
+    const bool ragged = (ntok & 31) != 0;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
+    __syncthreads();
+
+    for (int o0 = wave * 32; o0 < ntok; o0 += NW * 32) {     // the wave's 32 owner rows (queries / keys)
+        const int orow = o0 + r;
+        const int oc = orow < ntok ? orow : ntok - 1;         // padded rows re-read the last row; never stored
+        bf16x8 t1[KS], t2[KS];
+        float Lc = 0.f, Dc = 0.f;
+        {
+            const bf16_t* p1 = (MODE == 0 ? Q : K) + (head_rows + oc) * HD + hh * 8;
+            const bf16_t* p2 = MODE == 0 ? do_head + (size_t)oc * ctx_stride + hh * 8 : V + (head_rows + oc) * HD + hh * 8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                t1[ks] = *reinterpret_cast<const bf16x8*>(p1 + ks * 16);
+                t2[ks] = *reinterpret_cast<const bf16x8*>(p2 + ks * 16);
+            }
+            if constexpr (MODE == 0) {
+                const bf16_t* po = o_head + (size_t)oc * ctx_stride + hh * 8;
+                float acc = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 ov = *reinterpret_cast<const bf16x8*>(po + ks * 16);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc += (float)t2[ks][j] * (float)ov[j];
+                }
+                Dc = acc + __shfl_xor(acc, 32, 64);           // the other half-wave holds the other 32 columns
+                Lc = LSE[head_rows + oc];
+                if (hh == 0 && orow < ntok) Dbuf[head_rows + orow] = Dc;
+            }
+        }
+        f32x16 out1[DB], out2[DB];
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                out1[d][i] = 0.f;
+                out2[d][i] = 0.f;
+            }
+
+        for (int rb = 0; rb < blocks; ++rb) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                s[i] = 0.f;
+                dp[i] = 0.f;
+            }
+            const int row = rb * 32 + r;
+            const int sw = swz(row);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(r1 + row * RB + (((ks * 2 + hh) ^ sw) << 4));
+                const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(r2 + row * RB + (((ks * 2 + hh) ^ sw) << 4));
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, t1[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, t2[ks], dp, 0, 0, 0);
+            }
+            // element i of a lane: resident row rb*32 + 8 (i >> 2) + 4 hh + (i & 3), owner row = the lane's
+            f32x16 pr;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 l4, d4;
+                if constexpr (MODE == 1) {
+                    l4 = *reinterpret_cast<const f32x4*>(l_lds + rb * 32 + 8 * g + 4 * hh);
+                    d4 = *reinterpret_cast<const f32x4*>(d_lds + rb * 32 + 8 * g + 4 * hh);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = 4 * g + j;
+                    const float lc = MODE == 1 ? l4[j] : Lc;
+                    const float dc = MODE == 1 ? d4[j] : Dc;
+                    float p = __builtin_amdgcn_exp2f(fmaf(s[i], c, -lc));
+                    if (MODE == 0 && ragged && rb == blocks - 1 && rb * 32 + 8 * g + 4 * hh + j >= ntok) p = 0.f;
+                    pr[i] = p;
+                    s[i] = p * (dp[i] - dc) * scale;          // dS (scaled): s is reused
+                }
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                u32x4 dk = {pack_bf16(s[8 * st + 0], s[8 * st + 1]), pack_bf16(s[8 * st + 2], s[8 * st + 3]),
+                            pack_bf16(s[8 * st + 4], s[8 * st + 5]), pack_bf16(s[8 * st + 6], s[8 * st + 7])};
+                const bf16x8 dsf = __builtin_bit_cast(bf16x8, dk);
+                u32x4 pk = {pack_bf16(pr[8 * st + 0], pr[8 * st + 1]), pack_bf16(pr[8 * st + 2], pr[8 * st + 3]),
+                            pack_bf16(pr[8 * st + 4], pr[8 * st + 5]), pack_bf16(pr[8 * st + 6], pr[8 * st + 7])};
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+                const int ka = rb * 32 + 16 * st + 4 * hh + tq, kb = ka + 8;
+#pragma unroll
+                for (int d = 0; d < DB; ++d) {
+                    const int chunk = d * 4 + tsub * 2 + (tp >> 1);
+                    const int oa = ka * RB + ((chunk ^ swz(ka)) << 4) + (tp & 1) * 8;
+                    const int ob = kb * RB + ((chunk ^ swz(kb)) << 4) + (tp & 1) * 8;
+                    const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_b*)(r1 + oa));
+                    const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_b*)(r1 + ob));
+                    const bf16x8 af = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    out1[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, dsf, out1[d], 0, 0, 0);
+                    if constexpr (MODE == 1) {
+                        const bf16x4 w0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_b*)(r2 + oa));
+                        const bf16x4 w1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_b*)(r2 + ob));
+                        const bf16x8 bf = __builtin_shufflevector(w0, w1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        out2[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, pf, out2[d], 0, 0, 0);
+                    }
+                }
+            }
+        }
+
+        // ---- store: lane holds owner row orow, columns d = 32 blk + 8 g + 4 hh + (0..3)
+        if (orow < ntok) {
+            bf16_t* base = dqkv + (((size_t)b * ntok + orow) * 3 * heads + h) * HD + 4 * hh;
+            const size_t which_stride = (size_t)heads * HD;
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2 a = {pack_bf16(out1[d][4 * g], out1[d][4 * g + 1]), pack_bf16(out1[d][4 * g + 2], out1[d][4 * g + 3])};
+                    *reinterpret_cast<u32x2*>(base + (MODE == 0 ? 0 : 1) * which_stride + d * 32 + 8 * g) = a;
+                    if constexpr (MODE == 1) {
+                        u32x2 v2 = {pack_bf16(out2[d][4 * g], out2[d][4 * g + 1]), pack_bf16(out2[d][4 * g + 2], out2[d][4 * g + 3])};
+                        *reinterpret_cast<u32x2*>(base + 2 * which_stride + d * 32 + 8 * g) = v2;
+                    }
+                }
+        }
+    }
+}
+
+int attention_bwd_max_tokens() { return 576; }               // two resident [ntok, 64] bf16 matrices + L, D within 160 KiB
+
+template <int NW>
+static hipError_t attn_bwd_launch(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                                  const float* lse, float* dbuf, void* dqkv, int batch, int heads, int ntok, float scale,
+                                  hipStream_t s) {
+    const int npad = ((ntok + 31) / 32) * 32;
+    const size_t lds0 = (size_t)2 * npad * 128, lds1 = lds0 + (size_t)2 * npad * 4;
+    auto k0 = &attention_bwd<0, NW>;
+    auto k1 = &attention_bwd<1, NW>;
+    if (lds1 > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        if (e != hipSuccess) return e;
+    }
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(q);
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(k);
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(v);
+    const bf16_t* O = reinterpret_cast<const bf16_t*>(o);
+    const bf16_t* DO = reinterpret_cast<const bf16_t*>(d_o);
+    bf16_t* G = reinterpret_cast<bf16_t*>(dqkv);
+    hipLaunchKernelGGL(k0, dim3(batch * heads), dim3(NW * 64), lds0, s, Q, K, V, O, DO, lse, dbuf, G, ntok, heads, scale);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k1, dim3(batch * heads), dim3(NW * 64), lds1, s, Q, K, V, O, DO, lse, dbuf, G, ntok, heads, scale);
+    return hipGetLastError();
+}
+
+hipError_t launch_attention_backward(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                                     const float* lse, float* dbuf, void* dqkv, int batch, int heads, int ntok, int hd,
+                                     float scale, hipStream_t s) {
+    if (hd != 64 || ntok < 1 || ntok > attention_bwd_max_tokens()) return hipErrorInvalidValue;
+    const int tiles = (ntok + 31) / 32;
+    int nw = 4;
+    long best = -1;
+    for (int cnd : {4, 5, 6, 7, 8}) {
+        const int rounds = (tiles + cnd - 1) / cnd;
+        const long util = 1000L * tiles / (rounds * cnd);
+        if (util >= best) { best = util; nw = cnd; }
+    }
+    switch (nw) {
+        case 4: return attn_bwd_launch<4>(q, k, v, o, d_o, lse, dbuf, dqkv, batch, heads, ntok, scale, s);
+        case 5: return attn_bwd_launch<5>(q, k, v, o, d_o, lse, dbuf, dqkv, batch, heads, ntok, scale, s);
+        case 6: return attn_bwd_launch<6>(q, k, v, o, d_o, lse, dbuf, dqkv, batch, heads, ntok, scale, s);
+        case 7: return attn_bwd_launch<7>(q, k, v, o, d_o, lse, dbuf, dqkv, batch, heads, ntok, scale, s);
+        default: return attn_bwd_launch<8>(q, k, v, o, d_o, lse, dbuf, dqkv, batch, heads, ntok, scale, s);
+    }
+}
+
+}  // namespace vitk

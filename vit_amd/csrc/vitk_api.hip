@@ -195,20 +195,47 @@ int vitk_qkv_proj(const void* A, const void* W, const float* bias, void* qkv, in
                     "vitk_qkv_proj");
 }
 
-int vitk_attention(const void* q, const void* k, const void* v, void* ctx, int batch, int heads, int ntok,
-                   int hd, float scale, void* stream) {
-    if (!q || !k || !v || !ctx) return fail(VITK_ERR_INVALID, "vitk_attention: null pointer");
-    if (batch <= 0 || heads <= 0 || ntok <= 0) return fail(VITK_ERR_INVALID, "vitk_attention: non-positive size");
+static int attention_forward(const char* name, const void* q, const void* k, const void* v, void* ctx, float* lse,
+                             int batch, int heads, int ntok, int hd, float scale, void* stream) {
+    if (!q || !k || !v || !ctx) return fail(VITK_ERR_INVALID, "%s: null pointer", name);
+    if (batch <= 0 || heads <= 0 || ntok <= 0) return fail(VITK_ERR_INVALID, "%s: non-positive size", name);
     if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(ctx))
-        return fail(VITK_ERR_INVALID, "vitk_attention: pointers must be 16-byte aligned");
+        return fail(VITK_ERR_INVALID, "%s: pointers must be 16-byte aligned", name);
     if (hd != 64 && hd != 80 && hd != 96)
-        return fail(VITK_ERR_UNSUPPORTED, "vitk_attention: hd=%d (64, 80 and 96 are implemented)", hd);
+        return fail(VITK_ERR_UNSUPPORTED, "%s: hd=%d (64, 80 and 96 are implemented)", name, hd);
     if (ntok > attention_max_tokens(hd))
-        return fail(VITK_ERR_UNSUPPORTED, "vitk_attention: ntok=%d exceeds the limit %d at hd=%d", ntok,
+        return fail(VITK_ERR_UNSUPPORTED, "%s: ntok=%d exceeds the limit %d at hd=%d", name, ntok,
                     attention_max_tokens(hd), hd);
     return launched(launch_attention(q, k, v, ctx, batch, heads, ntok, hd, scale, g_attn_variant,
-                                     reinterpret_cast<hipStream_t>(stream)),
-                    "vitk_attention");
+                                     reinterpret_cast<hipStream_t>(stream), lse),
+                    name);
+}
+
+int vitk_attention(const void* q, const void* k, const void* v, void* ctx, int batch, int heads, int ntok,
+                   int hd, float scale, void* stream) {
+    return attention_forward("vitk_attention", q, k, v, ctx, nullptr, batch, heads, ntok, hd, scale, stream);
+}
+
+int vitk_attention_lse(const void* q, const void* k, const void* v, void* ctx, float* lse, int batch, int heads,
+                       int ntok, int hd, float scale, void* stream) {
+    if (!lse) return fail(VITK_ERR_INVALID, "vitk_attention_lse: null pointer");
+    return attention_forward("vitk_attention_lse", q, k, v, ctx, lse, batch, heads, ntok, hd, scale, stream);
+}
+
+int vitk_attention_backward(const void* q, const void* k, const void* v, const void* ctx, const void* dctx,
+                            const float* lse, float* dbuf, void* dqkv, int batch, int heads, int ntok, int hd,
+                            float scale, void* stream) {
+    if (!q || !k || !v || !ctx || !dctx || !lse || !dbuf || !dqkv)
+        return fail(VITK_ERR_INVALID, "vitk_attention_backward: null pointer");
+    if (batch <= 0 || heads <= 0 || ntok <= 0) return fail(VITK_ERR_INVALID, "vitk_attention_backward: non-positive size");
+    if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(ctx) || !aligned16(dctx) || !aligned16(dqkv))
+        return fail(VITK_ERR_INVALID, "vitk_attention_backward: pointers must be 16-byte aligned");
+    if (hd != 64) return fail(VITK_ERR_UNSUPPORTED, "vitk_attention_backward: hd=%d (64 is implemented)", hd);
+    if (ntok > attention_bwd_max_tokens())
+        return fail(VITK_ERR_UNSUPPORTED, "vitk_attention_backward: ntok=%d exceeds the limit %d", ntok, attention_bwd_max_tokens());
+    return launched(launch_attention_backward(q, k, v, ctx, dctx, lse, dbuf, dqkv, batch, heads, ntok, hd, scale,
+                                              reinterpret_cast<hipStream_t>(stream)),
+                    "vitk_attention_backward");
 }
 
 // ---- fp32 compute mode ------------------------------------------------------------------------

@@ -56,8 +56,12 @@ hipError_t launch_pos_embed_scale(const float* in, float* out, int g, int G, int
 hipError_t launch_cast_f32_bf16(const float* in, void* out, int64_t n, hipStream_t s);
 int attention_max_tokens(int hd);
 hipError_t launch_attention(const void* q, const void* k, const void* v, void* out, int batch, int heads,
-                            int ntok, int hd, float scale, int variant, hipStream_t s);
+                            int ntok, int hd, float scale, int variant, hipStream_t s, float* lse = nullptr);
 
+int attention_bwd_max_tokens();
+hipError_t launch_attention_backward(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                                     const float* lse, float* dbuf, void* dqkv, int batch, int heads, int ntok, int hd,
+                                     float scale, hipStream_t s);
 hipError_t launch_gemm_f32(const float* A, const float* W, const float* bias, const float* resid, float* out, int M,
                            int N, int K, int epilogue, hipStream_t s);
 hipError_t launch_qkv_f32(const float* A, const float* W, const float* bias, float* qkv, int batch, int ntok,

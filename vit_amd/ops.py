@@ -361,3 +361,37 @@ def gemm_tn(g, x, out=None):
         _lib.check(L.vitk_gemm_tn(_ptr(g), _ptr(x), _ptr(out), _ptr(ws) if need > 0 else None, ws.numel() if need > 0 else 0,
                                   M, N, R, _stream()), L)
     return out
+
+
+def attention_lse(qkv, ctx, scale):
+    """attention() that also returns the per-row log-sum-exp (f32 [B, H, N]) the backward kernel needs."""
+    L = _lib.load()
+    _chk(qkv, torch.bfloat16, "qkv")
+    _chk(ctx, torch.bfloat16, "ctx")
+    _, B, H, N, hd = qkv.shape
+    lse = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
+    with _span("attention"):
+        _lib.check(L.vitk_attention_lse(_ptr(qkv[0]), _ptr(qkv[1]), _ptr(qkv[2]), _ptr(ctx), _ptr(lse), B, H, N, hd,
+                                        float(scale), _stream()), L)
+    return lse
+
+
+def attention_backward_supported(N, hd):
+    return hd == 64 and N <= 576
+
+
+def attention_backward(qkv, ctx, dctx, lse, scale):
+    """Gradient of attention() w.r.t. q, k, v as one bf16 [B, N, 3, H, hd] tensor."""
+    L = _lib.load()
+    for t, n in ((qkv, "qkv"), (ctx, "ctx"), (dctx, "dctx")):
+        _chk(t, torch.bfloat16, n)
+    _chk(lse, torch.float32, "lse")
+    _, B, H, N, hd = qkv.shape
+    if ctx.shape != (B, N, H * hd) or dctx.shape != ctx.shape or lse.shape != (B, H, N):
+        raise _lib.VitkError(f"attention_backward: ctx {tuple(ctx.shape)}, dctx {tuple(dctx.shape)}, lse {tuple(lse.shape)}")
+    dbuf = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
+    dqkv = torch.empty(B, N, 3, H, hd, dtype=torch.bfloat16, device=qkv.device)
+    with _span("attention_backward"):
+        _lib.check(L.vitk_attention_backward(_ptr(qkv[0]), _ptr(qkv[1]), _ptr(qkv[2]), _ptr(ctx), _ptr(dctx), _ptr(lse),
+                                             _ptr(dbuf), _ptr(dqkv), B, H, N, hd, float(scale), _stream()), L)
+    return dqkv

@@ -208,6 +208,11 @@ int vitk_attention_backward(const void* q, const void* k, const void* v, const v
                             const float* lse, float* dbuf, void* dqkv, int batch, int heads, int ntok, int hd,
                             float scale, void* stream);
 
+/* vitk_gemm_bias_gelu for the training step: also writes the pre-activation pre bf16 [M,N] = A W^T + bias, which
+ * GELU's backward needs.  N a multiple of 256, K of 64, M >= 128 (other shapes: VITK_ERR_UNSUPPORTED). */
+int vitk_gemm_bias_gelu_dual(const void* A, const void* W, const float* bias, void* pre, void* out, int M, int N, int K,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -190,3 +190,20 @@ def test_gpu_attention_backward_kernel(B, H, N):
         a, bb = got[:, :, w].float().cpu().double().reshape(-1), want[:, :, w].reshape(-1)
         cos = float(a @ bb / (a.norm() * bb.norm()))
         assert cos > 0.9995, (w, cos)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(300, 512, 128), (50432, 3072, 768), (8200, 1024, 192)])
+def test_gpu_gelu_gemm_with_pre_activation_output(M, N, K):
+    """vitk_gemm_bias_gelu_dual: out equals vitk_gemm_bias_gelu's bit for bit, pre equals vitk_gemm_bias's."""
+    from vit_amd import ops
+    gen = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=gen).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=gen) * 0.05).to(torch.bfloat16).cuda()
+    b = torch.randn(N, generator=gen).cuda()
+    want_out, want_pre = torch.empty(M, N, dtype=torch.bfloat16, device="cuda"), torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_bias_gelu(a, w, b, want_out)
+    ops.gemm_bias(a, w, b, want_pre)
+    out, pre = torch.full_like(want_out, float("nan")), torch.full_like(want_out, float("nan"))
+    ops.gemm_bias_gelu_dual(a, w, b, pre, out)
+    assert torch.equal(out, want_out) and torch.equal(pre, want_pre)

@@ -70,6 +70,7 @@ class LinearFn(torch.autograd.Function):
     def forward(ctx, a, weight, bias, w_cd, kind, resid):
         rows, n = a.shape[0], weight.shape[0]
         cd = a.dtype
+        pre = None
         b32 = None if bias is None else bias.detach()
         fp32 = cd == torch.float32
         out_dtype = torch.float32 if kind in ("resid", "logits") else cd
@@ -77,6 +78,9 @@ class LinearFn(torch.autograd.Function):
         if fp32:
             epi = {"bias": EPI_BIAS, "logits": EPI_BIAS, "gelu": EPI_GELU, "tanh": EPI_TANH, "resid": EPI_RESIDUAL}[kind]
             ops.gemm_f32(a, w_cd, b32, out, epi, resid=resid if kind == "resid" else None)
+        elif kind == "gelu" and ops.gemm_bias_gelu_dual_supported(rows, n, a.shape[1]):
+            pre = torch.empty_like(out)                       # kept for the backward instead of being recomputed
+            ops.gemm_bias_gelu_dual(a, w_cd, b32, pre, out)
         elif kind == "gelu":
             ops.gemm_bias_gelu(a, w_cd, b32, out)
         elif kind == "tanh":
@@ -87,7 +91,7 @@ class LinearFn(torch.autograd.Function):
             ops.gemm_bias(a, w_cd, b32, out)
         ctx.kind = kind
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(a, weight, bias, w_cd, out if kind == "tanh" else None)
+        ctx.save_for_backward(a, weight, bias, w_cd, out if kind == "tanh" else pre)
         return out
 
     @staticmethod
@@ -96,11 +100,11 @@ class LinearFn(torch.autograd.Function):
         cd = a.dtype
         g_resid = g if ctx.kind == "resid" else None
         if ctx.kind == "gelu":
-            # the pre-activation is recomputed (one more GEMM) instead of being stored by the forward
-            if cd == torch.bfloat16:
+            pre = out                                             # the forward's second output, when it had one
+            if pre is None and cd == torch.bfloat16:              # else recomputed with one more GEMM
                 pre = torch.empty(a.shape[0], weight.shape[0], dtype=cd, device=a.device)
                 ops.gemm_bias(a, w_cd, None if bias is None else bias.detach(), pre)
-            else:
+            elif pre is None:
                 pre = F.linear(a, w_cd, bias)
             g_pre = torch.ops.aten.gelu_backward(g, pre)                      # f32 math inside, cd in and out
         elif ctx.kind == "tanh":

@@ -249,6 +249,10 @@ hipError_t launch_gemm_tiled(const GemmArgs& a, int epilogue, bool gather, int v
     switch (epilogue) {
         case EPI_BIAS_BF16: return launch_variant<EPI_BIAS_BF16, false>(a, variant, s);
         case EPI_BIAS_GELU_BF16: return launch_variant<EPI_BIAS_GELU_BF16, false>(a, variant, s);
+        case EPI_BIAS_GELU_DUAL_BF16:      // through the persistent kernels only (their shared epilogue)
+            if (variant == 1 || variant == 3 || (size_t)(a.M + 256) * a.N * 4 >= (1ull << 32)) return hipErrorInvalidValue;
+            if (variant != 5 && gemm_pp_supports(a, false)) return launch_gemm_pp(a, EPI_BIAS_GELU_DUAL_BF16, s);
+            return launch_gemm_pipe(a, EPI_BIAS_GELU_DUAL_BF16, false, s);
         case EPI_BIAS_RESID_F32: return launch_variant<EPI_BIAS_RESID_F32, false>(a, variant, s);
         case EPI_QKV_BF16: return launch_variant<EPI_QKV_BF16, false>(a, variant, s);
         case EPI_BIAS_F32: return launch_variant<EPI_BIAS_F32, false>(a, variant, s);

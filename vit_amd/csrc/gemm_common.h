@@ -40,7 +40,8 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
                                               int nw, int my_mt, int row_limit, int lane) {
     const int fr = lane & 15, fq = lane >> 4;
     constexpr bool OUT_BF16 = (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_BIAS_TANH_BF16 ||
-                               EPI == EPI_QKV_BF16);
+                               EPI == EPI_QKV_BF16 || EPI == EPI_BIAS_GELU_DUAL_BF16);
+    constexpr bool DUAL = EPI == EPI_BIAS_GELU_DUAL_BF16;       // two trips through the window: pre-activation, then GELU
     if constexpr (OUT_BF16) {
         // window = 32 rows x 128 B.  8-byte piece (row r, chunk c, half h) lives at
         // 128 r + 16 (c ^ (r & 7)) + 8 (h ^ ((r >> 3) & 1)): conflict-free for the MFMA-layout
@@ -78,6 +79,10 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
         for (int pass = 0; pass < 4; ++pass) {
             if (MASKED && pass * 2 >= my_mt) break;
 #pragma unroll
+            for (int rep = 0; rep < (DUAL ? 2 : 1); ++rep) {
+            const bool gelu_now = EPI == EPI_BIAS_GELU_BF16 || (DUAL && rep == 1);
+            char* dst = reinterpret_cast<char*>((DUAL && rep == 0) ? p.out2 : p.out);
+#pragma unroll
             for (int m2 = 0; m2 < 2; ++m2) {
                 if (MASKED && pass * 2 + m2 >= my_mt) break;
                 const int r = m2 * 16 + fr;
@@ -85,7 +90,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
                 for (int nt = 0; nt < 4; ++nt) {
                     const f32x4 a = acc[nt][pass * 2 + m2];
                     float v0 = a[0] + b4[nt][0], v1 = a[1] + b4[nt][1], v2 = a[2] + b4[nt][2], v3 = a[3] + b4[nt][3];
-                    if constexpr (EPI == EPI_BIAS_GELU_BF16) {
+                    if (gelu_now) {
                         f32x2 g01 = {v0, v1}, g23 = {v2, v3};
                         gelu_erf_x4(g01, g23);
                         v0 = g01[0]; v1 = g01[1]; v2 = g23[0]; v3 = g23[1];
@@ -114,7 +119,8 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
                     off = (uint32_t)(mw + lr) * p.ldo + col_off;
                 }
                 if ((!MASKED || lr < row_limit) && !((p.order >> 22) & 1))      // debug bit 22: no stores (timing probe)
-                    *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.out) + off * 2u) = v;
+                    *reinterpret_cast<u32x4*>(dst + off * 2u) = v;
+            }
             }
         }
     } else {

@@ -213,6 +213,7 @@ hipError_t launch_gemm_pipe(const GemmArgs& a, int epilogue, bool gather, hipStr
     switch (epilogue) {
         case EPI_BIAS_BF16: return launch_pipe<EPI_BIAS_BF16, false>(a, s);
         case EPI_BIAS_GELU_BF16: return launch_pipe<EPI_BIAS_GELU_BF16, false>(a, s);
+        case EPI_BIAS_GELU_DUAL_BF16: return launch_pipe<EPI_BIAS_GELU_DUAL_BF16, false>(a, s);
         case EPI_BIAS_RESID_F32: return launch_pipe<EPI_BIAS_RESID_F32, false>(a, s);
         case EPI_QKV_BF16: return launch_pipe<EPI_QKV_BF16, false>(a, s);
         case EPI_BIAS_F32: return launch_pipe<EPI_BIAS_F32, false>(a, s);

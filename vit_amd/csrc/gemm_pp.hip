@@ -403,6 +403,7 @@ hipError_t launch_gemm_pp(const GemmArgs& a, int epilogue, hipStream_t s) {
     switch (epilogue) {
         case EPI_BIAS_BF16: return launch_pp<EPI_BIAS_BF16>(a, s);
         case EPI_BIAS_GELU_BF16: return launch_pp<EPI_BIAS_GELU_BF16>(a, s);
+        case EPI_BIAS_GELU_DUAL_BF16: return launch_pp<EPI_BIAS_GELU_DUAL_BF16>(a, s);
         case EPI_BIAS_RESID_F32: return launch_pp<EPI_BIAS_RESID_F32>(a, s);
         case EPI_QKV_BF16: return launch_pp<EPI_QKV_BF16>(a, s);
         case EPI_BIAS_F32: return launch_pp<EPI_BIAS_F32>(a, s);

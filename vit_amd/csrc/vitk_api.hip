@@ -356,4 +356,22 @@ int vitk_gemm_tn(const void* G, const void* X, float* C, float* workspace, int64
     return launched(launch_gemm_tn(G, X, C, workspace, M, N, R, M, N, reinterpret_cast<hipStream_t>(stream)), "vitk_gemm_tn");
 }
 
+int vitk_gemm_bias_gelu_dual(const void* A, const void* W, const float* bias, void* pre, void* out, int M, int N, int K,
+                             void* stream) {
+    const char* name = "vitk_gemm_bias_gelu_dual";
+    if (!A || !W || !pre || !out) return fail(VITK_ERR_INVALID, "%s: null pointer", name);
+    if (M <= 0 || N <= 0 || K <= 0) return fail(VITK_ERR_INVALID, "%s: non-positive size %dx%dx%d", name, M, N, K);
+    if (!aligned16(A) || !aligned16(W) || !aligned16(pre) || !aligned16(out) || (bias && !aligned16(bias)))
+        return fail(VITK_ERR_INVALID, "%s: pointers must be 16-byte aligned", name);
+    if (N % 256 != 0 || K % 64 != 0 || M < 128)
+        return fail(VITK_ERR_UNSUPPORTED, "%s: M=%d N=%d K=%d (N a multiple of 256, K of 64, M >= 128)", name, M, N, K);
+    GemmArgs a = {};
+    a.A = A; a.W = W; a.bias = bias; a.out = out; a.out2 = pre;
+    a.M = M; a.N = N; a.K = K; a.lda = K; a.ldo = N;
+    a.order = g_gemm_variant >> 4;
+    hipError_t e = launch_gemm_tiled(a, EPI_BIAS_GELU_DUAL_BF16, false, g_gemm_variant & 15, reinterpret_cast<hipStream_t>(stream));
+    if (e == hipErrorInvalidValue) return fail(VITK_ERR_UNSUPPORTED, "%s: not available with this kernel variant / size", name);
+    return launched(e, name);
+}
+
 }  // extern "C"

@@ -13,6 +13,7 @@ enum Epilogue {
     EPI_PATCH_F32 = 4,       // out f32  [B,Ntok,N] row b*Ntok+1+p = acc + bias + pos[1+p]
     EPI_BIAS_F32 = 5,        // out f32  [M,N] = acc + bias
     EPI_BIAS_TANH_BF16 = 6,  // out bf16 [M,N] = tanh(acc + bias)
+    EPI_BIAS_GELU_DUAL_BF16 = 7,  // training: out = gelu(acc + bias) and out2 bf16 [M,N] = acc + bias (the pre-activation)
 };
 
 // epilogues of the fp32-mode GEMM (f32path.hip)
@@ -23,6 +24,7 @@ struct GemmArgs {
     const void* W;       // bf16 weights [N,K], row-major
     const float* bias;   // [N] or nullptr
     void* out;
+    void* out2;          // EPI_BIAS_GELU_DUAL_BF16: the pre-activation
     const float* resid;  // EPI_BIAS_RESID_F32 (may alias out)
     const float* pos;    // EPI_PATCH_F32: pos_embed [Ntok,N]
     int M, N, K;

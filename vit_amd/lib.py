@@ -36,6 +36,7 @@ SIGNATURES = {
     "vitk_pos_embed_scale": [_p, _p, _i, _i, _i, _p],
     "vitk_normalize_u8": [_p, _p, _i, _i, _i, _p, _p, _i, _p],
     "vitk_target_rank": [_p, _p, _p, _i, _i, _p],
+    "vitk_gemm_bias_gelu_dual": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     "vitk_attention_lse": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "vitk_attention_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "vitk_gemm_tn": [_p, _p, _p, _p, _i64, _i, _i, _i, _p],

@@ -395,3 +395,20 @@ def attention_backward(qkv, ctx, dctx, lse, scale):
         _lib.check(L.vitk_attention_backward(_ptr(qkv[0]), _ptr(qkv[1]), _ptr(qkv[2]), _ptr(ctx), _ptr(dctx), _ptr(lse),
                                              _ptr(dbuf), _ptr(dqkv), B, H, N, hd, float(scale), _stream()), L)
     return dqkv
+
+
+def gemm_bias_gelu_dual_supported(M, N, K):
+    return N % 256 == 0 and K % 64 == 0 and M >= 128
+
+
+def gemm_bias_gelu_dual(a, w, bias, pre, out):
+    """out = gelu(a w^T + bias) and pre = a w^T + bias (both bf16 [M, N])."""
+    L = _lib.load()
+    M, N, K = _dense_shapes(a, w, out, "gemm_bias_gelu_dual")
+    _chk(pre, torch.bfloat16, "pre")
+    _chk(out, torch.bfloat16, "out")
+    if pre.shape != out.shape:
+        raise _lib.VitkError("gemm_bias_gelu_dual: pre and out shapes differ")
+    with _span("gemm_bias_gelu"):
+        _lib.check(L.vitk_gemm_bias_gelu_dual(_ptr(a), _ptr(w), _ptr(bias), _ptr(pre), _ptr(out), M, N, K, _stream()), L)
+    return out

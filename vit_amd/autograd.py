@@ -186,13 +186,6 @@ class AttentionFn(torch.autograd.Function):
         return dqkv, None
 
 
-def _embed_torch(img, weight, bias, cls, pos, patch):
-    x = F.conv2d(img, weight.to(img.dtype), None, stride=patch).float()    # [B, D, gh, gw]
-    x = x.flatten(2).transpose(1, 2) + bias                                # [B, n, D]
-    x = torch.cat((cls.expand(x.shape[0], -1, -1), x), dim=1)
-    return x + pos
-
-
 class PatchEmbedFn(torch.autograd.Function):
     """x f32 [B, N, D] = cat(cls, conv(img) + bias) + pos (models/vision_transformer.py:47-50)."""
 
@@ -214,11 +207,23 @@ class PatchEmbedFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         img, weight, bias, cls, pos = ctx.saved_tensors
-        with torch.enable_grad():
-            ins = [t.detach().requires_grad_(True) for t in (weight, bias, cls, pos)]
-            out = _embed_torch(img, *ins, ctx.patch)
-            gw, gb, gc, gp = torch.autograd.grad(out, ins, g)
-        return None, gw, gb, gc, gp, None, None, None, None, None, None
+        P = ctx.patch
+        B, N, D = g.shape
+        gh, gw_ = img.shape[2] // P, img.shape[3] // P
+        # the convolution is a GEMM over the patch matrix (rows = patches, columns = (c, i, j) as the weight is
+        # flattened), so its weight gradient is the same dY^T X product as every Linear layer's
+        cols = img[:, :, :gh * P, :gw_ * P].reshape(B, 3, gh, P, gw_, P).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw_, 3 * P * P)
+        gp = g[:, 1:, :]
+        gp_cd = gp.reshape(B * (N - 1), D).to(img.dtype)
+        if img.dtype == torch.bfloat16 and ops.gemm_tn_supported(D, 3 * P * P, B * (N - 1)):
+            gw = ops.gemm_tn(gp_cd, cols.contiguous())
+        else:
+            gw = (gp_cd.t() @ cols).float()
+        gb = gp.sum((0, 1))
+        gc = g[:, 0, :].sum(0).view(1, 1, D)
+        gpos = g.sum(0, keepdim=True)
+        return None, gw.view(weight.shape).to(weight.dtype), gb.to(bias.dtype), gc.to(cls.dtype), gpos.to(pos.dtype), \
+            None, None, None, None, None, None
 
 
 def forward_train(model, x):

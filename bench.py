@@ -134,7 +134,7 @@ def main():
         # as in main.py:125-126
         model.train()
         net = model
-        if world > 1 and not share:
+        if world > 1:       # over RCCL in the real launch; over gloo when rehearsing several ranks on one GPU
             net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True)
         opt = torch.optim.AdamW(model.parameters(), 1e-3, weight_decay=0.03, fused=True)
         crit = torch.nn.CrossEntropyLoss()

@@ -213,6 +213,11 @@ int vitk_attention_backward(const void* q, const void* k, const void* v, const v
 int vitk_gemm_bias_gelu_dual(const void* A, const void* W, const float* bias, void* pre, void* out, int M, int N, int K,
                              void* stream);
 
+/* Bias gradient of a Linear layer in the training step: out[m] = sum_r G[r][m] with f32 accumulation; G bf16
+ * [R, M] contiguous, M a multiple of 256.  partials: caller's scratch, f32 [partial_rows, M]; up to
+ * min(partial_rows, 256) row chunks are summed separately and added in a fixed order. */
+int vitk_colsum_bf16(const void* G, float* out, float* partials, int partial_rows, int R, int M, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -207,3 +207,14 @@ def test_gpu_gelu_gemm_with_pre_activation_output(M, N, K):
     out, pre = torch.full_like(want_out, float("nan")), torch.full_like(want_out, float("nan"))
     ops.gemm_bias_gelu_dual(a, w, b, pre, out)
     assert torch.equal(out, want_out) and torch.equal(pre, want_pre)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,M", [(1, 256), (102, 768), (5000, 1024), (50432, 2304), (50432, 3072)])
+def test_gpu_bias_gradient_column_sum(R, M):
+    from vit_amd import ops
+    g = torch.randn(R, M, generator=torch.Generator().manual_seed(R + M)).to(torch.bfloat16).cuda()
+    got = ops.colsum(g)
+    want = g.double().sum(0)
+    assert (got.double() - want).abs().max() <= 1e-5 * max(1.0, R ** 0.5) * 4
+    assert torch.equal(got, ops.colsum(g))

@@ -58,7 +58,12 @@ def _linear_backward(g_pre, a, w_cd, weight, bias):
         gw = ops.gemm_tn(g_pre.contiguous(), a.contiguous()).to(weight.dtype)       # HIP: split-k dY^T X, f32 out
     else:
         gw = (g_pre.t() @ a).to(weight.dtype)
-    gb = None if bias is None else g_pre.sum(0, dtype=torch.float32).to(bias.dtype)
+    if bias is None:
+        gb = None
+    elif g_pre.dtype == torch.bfloat16 and g_pre.shape[1] % 256 == 0:
+        gb = ops.colsum(g_pre.contiguous()).to(bias.dtype)
+    else:
+        gb = g_pre.sum(0, dtype=torch.float32).to(bias.dtype)
     return ga, gw, gb
 
 

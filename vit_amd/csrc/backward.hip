@@ -164,4 +164,69 @@ hipError_t launch_layernorm_backward(const float* x, int64_t x_row_stride, const
     }
 }
 
+// ---------------------------------------------------------------------------
+// Bias gradient of a Linear layer: out[m] = sum_r G[r][m], G bf16 [R, M] (M a multiple of 256), f32
+// accumulation.  Block (x, y) takes 256 columns and the y-th chunk of rows: a half-wave reads one row's
+// 512 bytes, 8 columns per lane, the block's 8 half-waves walk the chunk's rows; their sums are added in a
+// fixed order in LDS and written as one partial row; reduce_partial_rows adds the chunks in order.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_bf16_partial(const bf16_t* __restrict__ G, float* __restrict__ partials,
+                                                           int R, int M, int rows_per_chunk) {
+    __shared__ float red[8][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hw = wave * 2 + (lane >> 5);                    // half-wave 0..7
+    const int col = blockIdx.x * 256 + (lane & 31) * 8;
+    const int r0 = blockIdx.y * rows_per_chunk;
+    int r1 = r0 + rows_per_chunk;
+    r1 = r1 < R ? r1 : R;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int r = r0 + hw; r < r1; r += 8) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(G + (size_t)r * M + col);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[2 * j] += bf16_lo(v[j]);
+            acc[2 * j + 1] += bf16_hi(v[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[hw][(lane & 31) * 8 + j] = acc[j];
+    __syncthreads();
+    float t = red[0][threadIdx.x];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) t += red[j][threadIdx.x];
+    partials[(size_t)blockIdx.y * M + blockIdx.x * 256 + threadIdx.x] = t;
+}
+
+// out[c] = sum over n partial rows of `width` floats (width a multiple of 64), in row order
+__global__ __launch_bounds__(1024) void reduce_partial_rows(const float* __restrict__ partials, int n, int width,
+                                                            float* __restrict__ out) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    float acc = 0.f;
+    for (int b = w; b < n; b += 16) acc += partials[(size_t)b * width + col];
+    red[w][lane] = acc;
+    __syncthreads();
+    if (w == 0) {
+        float t = red[0][lane];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) t += red[j][lane];
+        out[col] = t;
+    }
+}
+
+hipError_t launch_colsum_bf16(const void* G, float* out, float* partials, int partial_rows, int R, int M, hipStream_t s) {
+    int chunks = (R + 63) / 64;
+    if (chunks > 256) chunks = 256;
+    if (chunks > partial_rows) chunks = partial_rows;
+    const int rows_per_chunk = (R + chunks - 1) / chunks;
+    chunks = (R + rows_per_chunk - 1) / rows_per_chunk;
+    hipLaunchKernelGGL(colsum_bf16_partial, dim3(M / 256, chunks), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(G),
+                       partials, R, M, rows_per_chunk);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(reduce_partial_rows, dim3(M / 64), dim3(1024), 0, s, partials, chunks, M, out);
+    return hipGetLastError();
+}
+
 }  // namespace vitk

@@ -374,4 +374,14 @@ int vitk_gemm_bias_gelu_dual(const void* A, const void* W, const float* bias, vo
     return launched(e, name);
 }
 
+int vitk_colsum_bf16(const void* G, float* out, float* partials, int partial_rows, int R, int M, void* stream) {
+    if (!G || !out || !partials) return fail(VITK_ERR_INVALID, "vitk_colsum_bf16: null pointer");
+    if (R <= 0 || M <= 0 || partial_rows <= 0) return fail(VITK_ERR_INVALID, "vitk_colsum_bf16: non-positive size");
+    if (M % 256 != 0) return fail(VITK_ERR_UNSUPPORTED, "vitk_colsum_bf16: M=%d is not a multiple of 256", M);
+    if (!aligned16(G) || !aligned16(out) || !aligned16(partials))
+        return fail(VITK_ERR_INVALID, "vitk_colsum_bf16: pointers must be 16-byte aligned");
+    return launched(launch_colsum_bf16(G, out, partials, partial_rows, R, M, reinterpret_cast<hipStream_t>(stream)),
+                    "vitk_colsum_bf16");
+}
+
 }  // extern "C"

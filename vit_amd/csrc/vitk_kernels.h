@@ -50,6 +50,7 @@ hipError_t launch_layernorm_backward(const float* x, int64_t x_row_stride, const
 int gemm_tn_splits(int M, int N, int R);
 hipError_t launch_gemm_tn(const void* G, const void* X, float* C, float* part, int M, int N, int R, int ldg, int ldx,
                           hipStream_t s);
+hipError_t launch_colsum_bf16(const void* G, float* out, float* partials, int partial_rows, int R, int M, hipStream_t s);
 hipError_t launch_normalize_u8(const void* in, void* out, int64_t n, int64_t plane, const float* mean,
                                const float* std, bool out_bf16, hipStream_t s);
 hipError_t launch_target_rank(const float* logits, const int64_t* target, int* rank, int rows, int classes,

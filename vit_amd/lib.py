@@ -39,6 +39,7 @@ SIGNATURES = {
     "vitk_gemm_bias_gelu_dual": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     "vitk_attention_lse": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "vitk_attention_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
+    "vitk_colsum_bf16": [_p, _p, _p, _i, _i, _i, _p],
     "vitk_gemm_tn": [_p, _p, _p, _p, _i64, _i, _i, _i, _p],
     "vitk_layernorm_backward": [_p, _i64, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
 }

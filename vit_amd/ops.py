@@ -412,3 +412,20 @@ def gemm_bias_gelu_dual(a, w, bias, pre, out):
     with _span("gemm_bias_gelu"):
         _lib.check(L.vitk_gemm_bias_gelu_dual(_ptr(a), _ptr(w), _ptr(bias), _ptr(pre), _ptr(out), M, N, K, _stream()), L)
     return out
+
+
+_colsum_partials = {}
+
+
+def colsum(g):
+    """f32 [M] column sums of g bf16 [R, M] (the bias gradient of a Linear layer); M a multiple of 256."""
+    L = _lib.load()
+    _chk(g, torch.bfloat16, "g")
+    R, M = g.shape
+    part = _colsum_partials.get(g.device)
+    if part is None or part.numel() < 256 * M:
+        part = _colsum_partials[g.device] = torch.empty(256 * max(M, 4096), dtype=torch.float32, device=g.device)
+    out = torch.empty(M, dtype=torch.float32, device=g.device)
+    with _span("colsum"):
+        _lib.check(L.vitk_colsum_bf16(_ptr(g), _ptr(out), _ptr(part), 256, R, M, _stream()), L)
+    return out

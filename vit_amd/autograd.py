@@ -51,13 +51,24 @@ class LayerNormFn(torch.autograd.Function):
         return gx, gw.to(weight.dtype), gb.to(bias.dtype), None, None
 
 
+def _weight_grad(g, a):
+    """f32 [out, in] = g^T a for g [rows, out], a [rows, in]: the HIP split-k kernel on the rows that fill whole
+    64-row K tiles (bf16, out and in multiples of 256), a small library product for the remainder."""
+    g, a = g.contiguous(), a.contiguous()
+    rows = g.shape[0]
+    r64 = rows - rows % 64
+    if g.dtype == torch.bfloat16 and r64 > 0 and ops.gemm_tn_supported(g.shape[1], a.shape[1], r64):
+        gw = ops.gemm_tn(g[:r64], a[:r64])
+        if r64 < rows:
+            gw += (g[r64:].t() @ a[r64:]).float()
+        return gw
+    return (g.t() @ a).float()
+
+
 def _linear_backward(g_pre, a, w_cd, weight, bias):
     """g_pre [rows, out] in cd -> (grad a [rows, in] in cd, grad weight f32, grad bias f32)."""
     ga = g_pre @ w_cd
-    if g_pre.dtype == torch.bfloat16 and ops.gemm_tn_supported(g_pre.shape[1], a.shape[1], a.shape[0]):
-        gw = ops.gemm_tn(g_pre.contiguous(), a.contiguous()).to(weight.dtype)       # HIP: split-k dY^T X, f32 out
-    else:
-        gw = (g_pre.t() @ a).to(weight.dtype)
+    gw = _weight_grad(g_pre, a).to(weight.dtype)
     if bias is None:
         gb = None
     elif g_pre.dtype == torch.bfloat16 and g_pre.shape[1] % 256 == 0:
@@ -220,10 +231,7 @@ class PatchEmbedFn(torch.autograd.Function):
         cols = img[:, :, :gh * P, :gw_ * P].reshape(B, 3, gh, P, gw_, P).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw_, 3 * P * P)
         gp = g[:, 1:, :]
         gp_cd = gp.reshape(B * (N - 1), D).to(img.dtype)
-        if img.dtype == torch.bfloat16 and ops.gemm_tn_supported(D, 3 * P * P, B * (N - 1)):
-            gw = ops.gemm_tn(gp_cd, cols.contiguous())
-        else:
-            gw = (gp_cd.t() @ cols).float()
+        gw = _weight_grad(gp_cd, cols)
         gb = gp.sum((0, 1))
         gc = g[:, 0, :].sum(0).view(1, 1, D)
         gpos = g.sum(0, keepdim=True)

@@ -294,34 +294,34 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
             }
         } else {
 #pragma unroll
-        for (int u = 0; u < NB; ++u) {
+            for (int u = 0; u < NB; ++u) {
 #pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                u32x4 pk = {pack_bf16(s[u][8 * st + 0], s[u][8 * st + 1]), pack_bf16(s[u][8 * st + 2], s[u][8 * st + 3]),
-                            pack_bf16(s[u][8 * st + 4], s[u][8 * st + 5]), pack_bf16(s[u][8 * st + 6], s[u][8 * st + 7])};
-                const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+                for (int st = 0; st < 2; ++st) {
+                    u32x4 pk = {pack_bf16(s[u][8 * st + 0], s[u][8 * st + 1]), pack_bf16(s[u][8 * st + 2], s[u][8 * st + 3]),
+                                pack_bf16(s[u][8 * st + 4], s[u][8 * st + 5]), pack_bf16(s[u][8 * st + 6], s[u][8 * st + 7])};
+                    const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
 #pragma unroll
-                for (int d = 0; d < DB; ++d) {
-                    bf16x4 v0, v1;
-                    const int keyb = (lb + u) * 32 + 16 * st + 4 * hh;   // + 8t + (0..3)
-                    if constexpr (VTR) {
-                        const int chunk = d * 4 + tsub * 2 + (tp >> 1);
-                        const int ka = keyb + tq, kb2 = keyb + 8 + tq;
-                        const char* a0 = v_lds + ka * RB + ((chunk ^ v_swz(ka)) << 4) + (tp & 1) * 8;
-                        const char* a1 = v_lds + kb2 * RB + ((chunk ^ v_swz(kb2)) << 4) + (tp & 1) * 8;
-                        v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a0);
-                        v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a1);
-                    } else {
-                        const bf16_t* vt = reinterpret_cast<const bf16_t*>(v_lds) + (d * 32 + r) * vts + keyb;
-                        v0 = *reinterpret_cast<const bf16x4*>(vt);
-                        v1 = *reinterpret_cast<const bf16x4*>(vt + 8);
+                    for (int d = 0; d < DB; ++d) {
+                        bf16x4 v0, v1;
+                        const int keyb = (lb + u) * 32 + 16 * st + 4 * hh;   // + 8t + (0..3)
+                        if constexpr (VTR) {
+                            const int chunk = d * 4 + tsub * 2 + (tp >> 1);
+                            const int ka = keyb + tq, kb2 = keyb + 8 + tq;
+                            const char* a0 = v_lds + ka * RB + ((chunk ^ v_swz(ka)) << 4) + (tp & 1) * 8;
+                            const char* a1 = v_lds + kb2 * RB + ((chunk ^ v_swz(kb2)) << 4) + (tp & 1) * 8;
+                            v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a0);
+                            v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a1);
+                        } else {
+                            const bf16_t* vt = reinterpret_cast<const bf16_t*>(v_lds) + (d * 32 + r) * vts + keyb;
+                            v0 = *reinterpret_cast<const bf16x4*>(vt);
+                            v1 = *reinterpret_cast<const bf16x4*>(vt + 8);
+                        }
+                        const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o_acc[d], 0, 0, 0);
                     }
-                    const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o_acc[d], 0, 0, 0);
+                    if constexpr (MSUM) l_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, l_acc, 0, 0, 0);
                 }
-                if constexpr (MSUM) l_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, l_acc, 0, 0, 0);
             }
-        }
         }
     };
     using C1 = std::integral_constant<int, 1>;

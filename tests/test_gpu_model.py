@@ -121,3 +121,17 @@ def test_unsupported_head_dim_is_rejected_not_faked():
     ctx = torch.empty(1, 197, 96, dtype=torch.bfloat16, device=DEV)
     with pytest.raises(vit_amd.VitkError, match="hd=48"):
         ops.attention(qkv, ctx, 48 ** -0.5)
+
+
+def test_channels_last_model_and_images_as_the_reference_driver_passes_them():
+    """main.py:52 moves the model with `.cuda().to(memory_format=...)` and the loader can hand channels_last
+    images: both are strided views of the same values, so the logits must not change."""
+    meta, g = load_golden("s16_224_ref")
+    cfg, sd, x = golden_inputs(meta)
+    m = build_model("s16", 224, sd, DEV)
+    xd = x[:2].to(DEV)
+    with torch.no_grad():
+        y0 = m(xd).clone()
+        m = m.to(memory_format=torch.channels_last)
+        y1 = m(xd.to(memory_format=torch.channels_last))
+    assert torch.equal(y0, y1)

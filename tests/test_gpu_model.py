@@ -135,3 +135,18 @@ def test_channels_last_model_and_images_as_the_reference_driver_passes_them():
         m = m.to(memory_format=torch.channels_last)
         y1 = m(xd.to(memory_format=torch.channels_last))
     assert torch.equal(y0, y1)
+
+
+def test_hip_graph_replay_matches_eager():
+    meta, g = load_golden("s16_224_ref")
+    cfg, sd, x = golden_inputs(meta)
+    m = build_model("s16", 224, sd, DEV)
+    xd = x[:3].to(DEV).to(torch.bfloat16)
+    with torch.no_grad():
+        want = m(xd)
+        gf = vit_amd.GraphedForward(m, xd)
+        assert torch.equal(gf(xd), want)
+        x2 = torch.flip(xd, dims=[0])
+        assert torch.equal(gf(x2), m(x2))
+    with pytest.raises(vit_amd.VitkError):
+        gf(xd[:2])

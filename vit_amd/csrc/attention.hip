@@ -29,7 +29,6 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
 
 constexpr float kMaskedScore = -1.0e30f;
-static float* g_attn_lse = nullptr;   // optional per-row log-sum-exp output of the launch being prepared
 static int g_attn_probe = 0;   // timing probes (debug variant bits 2..4): K/V of head 0, no key loop, no stores
 
 // VTR = true : V row-major in LDS, transposed fragments via ds_read_b64_tr_b16.
@@ -458,7 +457,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
 
 template <int HD, int NW, bool VTR, bool STREAM, bool PD = false>
 static hipError_t attn_launch(const void* q, const void* k, const void* v, void* out, int batch, int heads,
-                              int ntok, float scale, hipStream_t s) {
+                              int ntok, float scale, hipStream_t s, float* lse) {
     const int kpad = ((ntok + 31) / 32) * 32;
     const int rb = HD == 64 ? 128 : 256;
     const size_t lds = STREAM ? (size_t)4 * 64 * rb
@@ -476,7 +475,7 @@ static hipError_t attn_launch(const void* q, const void* k, const void* v, void*
     hipLaunchKernelGGL((attention_fwd<HD, NW, VTR, STREAM, PD>), grid, block, lds, s,
                        reinterpret_cast<const bf16_t*>(q), reinterpret_cast<const bf16_t*>(k),
                        reinterpret_cast<const bf16_t*>(v), reinterpret_cast<bf16_t*>(out), ntok, heads,
-                       scale * 1.44269504088896340736f, g_attn_probe, nbh, g_attn_lse);
+                       scale * 1.44269504088896340736f, g_attn_probe, nbh, lse);
     return hipGetLastError();
 }
 
@@ -486,7 +485,6 @@ int attention_max_tokens(int hd) { return (hd == 64 || hd == 80 || hd == 96) ? 1
 
 hipError_t launch_attention(const void* q, const void* k, const void* v, void* out, int batch, int heads,
                             int ntok, int hd, float scale, int variant, hipStream_t s, float* lse) {
-    g_attn_lse = lse;
     if ((hd != 64 && hd != 80 && hd != 96) || ntok < 1) return hipErrorInvalidValue;
     const int qtiles = (ntok + 31) / 32;
     // variant: 0 = automatic (persistent workgroups with two resident K/V buffers when two heads fit in LDS,
@@ -521,16 +519,16 @@ hipError_t launch_attention(const void* q, const void* k, const void* v, void* o
     }
 #define VITK_ATTN_CASE(NWV)                                                                                   \
     case NWV:                                                                                                 \
-        if (hd == 96 && mode == 2) return attn_launch<96, NWV, true, true>(q, k, v, out, batch, heads, ntok, scale, s);  \
-        if (hd == 96 && mode == 0) return attn_launch<96, NWV, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s);  \
-        if (hd == 96) return attn_launch<96, NWV, true, false>(q, k, v, out, batch, heads, ntok, scale, s);   \
-        if (hd == 80 && mode == 2) return attn_launch<80, NWV, true, true>(q, k, v, out, batch, heads, ntok, scale, s);  \
-        if (hd == 80 && mode == 0) return attn_launch<80, NWV, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s);  \
-        if (hd == 80) return attn_launch<80, NWV, true, false>(q, k, v, out, batch, heads, ntok, scale, s);   \
-        if (mode == 2) return attn_launch<64, NWV, true, true>(q, k, v, out, batch, heads, ntok, scale, s);   \
-        if (mode == 0) return attn_launch<64, NWV, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s);  \
-        if (mode == 3) return attn_launch<64, NWV, true, false>(q, k, v, out, batch, heads, ntok, scale, s);  \
-        return attn_launch<64, NWV, false, false>(q, k, v, out, batch, heads, ntok, scale, s);
+        if (hd == 96 && mode == 2) return attn_launch<96, NWV, true, true>(q, k, v, out, batch, heads, ntok, scale, s, lse);  \
+        if (hd == 96 && mode == 0) return attn_launch<96, NWV, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s, lse);  \
+        if (hd == 96) return attn_launch<96, NWV, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse);   \
+        if (hd == 80 && mode == 2) return attn_launch<80, NWV, true, true>(q, k, v, out, batch, heads, ntok, scale, s, lse);  \
+        if (hd == 80 && mode == 0) return attn_launch<80, NWV, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s, lse);  \
+        if (hd == 80) return attn_launch<80, NWV, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse);   \
+        if (mode == 2) return attn_launch<64, NWV, true, true>(q, k, v, out, batch, heads, ntok, scale, s, lse);   \
+        if (mode == 0) return attn_launch<64, NWV, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s, lse);  \
+        if (mode == 3) return attn_launch<64, NWV, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse);  \
+        return attn_launch<64, NWV, false, false>(q, k, v, out, batch, heads, ntok, scale, s, lse);
     switch (nw) {
         VITK_ATTN_CASE(4)
         VITK_ATTN_CASE(5)
@@ -539,11 +537,11 @@ hipError_t launch_attention(const void* q, const void* k, const void* v, void* o
         VITK_ATTN_CASE(8)
         case 10:      // resident modes only
             // (head_dim 80 / 96 with two resident heads has at most 5 q-tiles: never 10 waves)
-            if (hd == 96) return attn_launch<96, 10, true, false>(q, k, v, out, batch, heads, ntok, scale, s);
-            if (hd == 80) return attn_launch<80, 10, true, false>(q, k, v, out, batch, heads, ntok, scale, s);
-            if (mode == 0) return attn_launch<64, 10, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s);
-            if (mode == 3) return attn_launch<64, 10, true, false>(q, k, v, out, batch, heads, ntok, scale, s);
-            return attn_launch<64, 10, false, false>(q, k, v, out, batch, heads, ntok, scale, s);
+            if (hd == 96) return attn_launch<96, 10, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse);
+            if (hd == 80) return attn_launch<80, 10, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse);
+            if (mode == 0) return attn_launch<64, 10, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s, lse);
+            if (mode == 3) return attn_launch<64, 10, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse);
+            return attn_launch<64, 10, false, false>(q, k, v, out, batch, heads, ntok, scale, s, lse);
     }
 #undef VITK_ATTN_CASE
     return hipErrorInvalidValue;

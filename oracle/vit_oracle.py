@@ -17,7 +17,6 @@ those vectors.
 All arithmetic here is PyTorch's (the reference pins no version; the vectors
 were captured with torch 2.10.0+rocm7.0 on CPU).
 """
-import math
 
 import torch
 import torch.nn.functional as F

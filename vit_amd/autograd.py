@@ -106,7 +106,6 @@ class LinearFn(torch.autograd.Function):
         else:
             ops.gemm_bias(a, w_cd, b32, out)
         ctx.kind = kind
-        ctx.has_bias = bias is not None
         ctx.save_for_backward(a, weight, bias, w_cd, out if kind == "tanh" else pre)
         return out
 

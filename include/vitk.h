@@ -180,10 +180,11 @@ int vitk_target_rank(const float* logits, const int64_t* target, int* rank, int 
  * main.py:207-218): dx[r, :] (f32 [rows, D], contiguous), dgamma, dbeta (f32 [D]) from x (f32, row r at
  * x + r*x_row_stride, as in the forward), gamma, and the output gradient g (bf16 or f32 [rows, D], g_dtype).
  * Mean and rstd are recomputed from x.  add (may be NULL): f32 [rows, D] added to dx, the gradient reaching x
- * along the residual branch (may alias dx).  partials: caller's scratch, f32 [partial_rows, 2, D]; the kernel uses
+ * along the residual branch (may alias dx).  dx_bf16 (may be NULL): dx again, rounded to bf16 [rows, D], for the
+ * backward GEMMs that take it as an operand.  partials: caller's scratch, f32 [partial_rows, 2, D]; the kernel uses
  * min(partial_rows, ceil(rows/4), 1024) workgroups, one partial each, added in a fixed order. */
 int vitk_layernorm_backward(const float* x, int64_t x_row_stride, const float* gamma, const void* g, int g_dtype,
-                            const float* add, float* dx, float* dgamma, float* dbeta, float* partials, int partial_rows, int rows,
+                            const float* add, float* dx, void* dx_bf16, float* dgamma, float* dbeta, float* partials, int partial_rows, int rows,
                             int D, float eps, void* stream);
 
 /* Weight gradient of a Linear layer in the training step: C[m][n] = sum_r G[r][m] * X[r][n] (dW = dY^T X, what

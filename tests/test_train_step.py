@@ -138,6 +138,9 @@ def test_gpu_layernorm_backward_kernel(rows, D, gdt):
     skip = torch.randn(rows, D, generator=gen)
     dx3, _, _ = ops.layernorm_backward(x.cuda(), gamma.cuda(), g.cuda(), 1e-6, add=skip.cuda())
     assert torch.allclose(dx3.cpu().double(), wx + skip.double(), rtol=1e-4, atol=2e-5)  # residual-branch gradient added
+    d16 = torch.empty(rows, D, dtype=torch.bfloat16, device="cuda")
+    dx4, _, _ = ops.layernorm_backward(x.cuda(), gamma.cuda(), g.cuda(), 1e-6, add=skip.cuda(), dx_bf16=d16)
+    assert torch.equal(dx4, dx3) and torch.equal(d16, dx3.to(torch.bfloat16))             # the bf16 copy of the same values
 
 
 @pytest.mark.gpu

@@ -25,6 +25,19 @@ def _vjp(fn, inputs, grad_out):
         return torch.autograd.grad(out, ins, grad_out)
 
 
+_handoff = [None]      # (f32 gradient, its bf16 copy) of the most recent LayerNorm backward
+
+
+def _as_operand(g, cd):
+    """g in the GEMM operand dtype: the copy the LayerNorm backward kernel already made, if g is that gradient."""
+    h = _handoff[0]
+    _handoff[0] = None
+    if h is not None and cd == torch.bfloat16 and h[0].data_ptr() == g.data_ptr() and h[0].shape == g.shape \
+            and g.dtype == torch.float32 and g.is_contiguous():
+        return h[1]
+    return g.to(cd)
+
+
 class LayerNormFn(torch.autograd.Function):
     """(y, x) with y = LayerNorm(x) in cd; x f32 [rows, D] (models/transformer.py:68,73,98).
 
@@ -47,7 +60,12 @@ class LayerNormFn(torch.autograd.Function):
         if g is None:                                                     # only the skip output was used
             return g_skip, None, None, None, None
         add = None if g_skip is None else g_skip.contiguous()
-        gx, gw, gb = ops.layernorm_backward(x, weight.detach(), g.contiguous(), ctx.eps, add=add)
+        gx16 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if g.dtype == torch.bfloat16 else None
+        gx, gw, gb = ops.layernorm_backward(x, weight.detach(), g.contiguous(), ctx.eps, add=add, dx_bf16=gx16)
+        # The Linear layer that produced x needs this gradient as a bf16 GEMM operand next: the kernel wrote that
+        # copy in the same pass.  Handed over out of band (autograd carries one tensor per edge); holding gx keeps
+        # its storage from being reused, so the pointer comparison at the consumer cannot match another tensor.
+        _handoff[0] = (gx, gx16) if gx16 is not None else None
         return gx, gw.to(weight.dtype), gb.to(bias.dtype), None, None
 
 
@@ -126,7 +144,7 @@ class LinearFn(torch.autograd.Function):
             o = out.float()
             g_pre = (g.float() * (1.0 - o * o)).to(cd)
         else:
-            g_pre = g.to(cd)
+            g_pre = _as_operand(g, cd)
         ga, gw, gb = _linear_backward(g_pre, a, w_cd, weight, bias)
         return ga, gw, gb, None, None, g_resid
 
@@ -240,6 +258,7 @@ class PatchEmbedFn(torch.autograd.Function):
 
 def forward_train(model, x):
     """The forward of vit_amd.VisionTransformer with autograd: same kernels, fresh tensors per op."""
+    _handoff[0] = None
     w = model._cache.get()
     fp32 = model.precision == "fp32"
     cd = torch.float32 if fp32 else torch.bfloat16

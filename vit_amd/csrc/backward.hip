@@ -20,8 +20,8 @@ template <int NV, bool G_BF16>
 __global__ __launch_bounds__(256) void layernorm_bwd_rows(const float* __restrict__ x, int64_t x_stride,
                                                           const float* __restrict__ gamma,
                                                           const void* __restrict__ g, const float* __restrict__ add,
-                                                          float* __restrict__ dx, float* __restrict__ partials, int rows,
-                                                          float eps) {
+                                                          float* __restrict__ dx, bf16_t* __restrict__ dx16,
+                                                          float* __restrict__ partials, int rows, float eps) {
     constexpr int D = NV * 256;
     __shared__ float red[4][2][D];
     const int lane = threadIdx.x & 63;
@@ -87,6 +87,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows(const float* __restric
             // a separate pass over both tensors
             if (add) o = o + *reinterpret_cast<const f32x4*>(add + (int64_t)row * D + i * 256 + lane * 4);
             *reinterpret_cast<f32x4*>(dx + (int64_t)row * D + i * 256 + lane * 4) = o;
+            if (dx16) {     // the same gradient as the bf16 operand of the backward GEMMs that consume it next
+                u32x2 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
+                *reinterpret_cast<u32x2*>(dx16 + (int64_t)row * D + i * 256 + lane * 4) = pk;
+            }
         }
     }
 #pragma unroll
@@ -134,16 +138,16 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_reduce(const float* __rest
 
 template <int NV>
 static hipError_t ln_bwd_launch(const float* x, int64_t xs, const float* gamma, const void* g, bool g_bf16,
-                                const float* add, float* dx,
+                                const float* add, float* dx, void* dx16,
                                 float* dgamma, float* dbeta, float* partials, int partial_rows, int rows, float eps,
                                 hipStream_t s) {
     int blocks = (rows + 3) / 4;
     if (blocks > 1024) blocks = 1024;
     if (blocks > partial_rows) blocks = partial_rows;
     if (g_bf16)
-        hipLaunchKernelGGL((layernorm_bwd_rows<NV, true>), dim3(blocks), dim3(256), 0, s, x, xs, gamma, g, add, dx, partials, rows, eps);
+        hipLaunchKernelGGL((layernorm_bwd_rows<NV, true>), dim3(blocks), dim3(256), 0, s, x, xs, gamma, g, add, dx, reinterpret_cast<bf16_t*>(dx16), partials, rows, eps);
     else
-        hipLaunchKernelGGL((layernorm_bwd_rows<NV, false>), dim3(blocks), dim3(256), 0, s, x, xs, gamma, g, add, dx, partials, rows, eps);
+        hipLaunchKernelGGL((layernorm_bwd_rows<NV, false>), dim3(blocks), dim3(256), 0, s, x, xs, gamma, g, add, dx, reinterpret_cast<bf16_t*>(dx16), partials, rows, eps);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     constexpr int D = NV * 256;
@@ -152,14 +156,14 @@ static hipError_t ln_bwd_launch(const float* x, int64_t xs, const float* gamma, 
 }
 
 hipError_t launch_layernorm_backward(const float* x, int64_t x_row_stride, const float* gamma, const void* g,
-                                     bool g_bf16, const float* add, float* dx, float* dgamma, float* dbeta, float* partials,
+                                     bool g_bf16, const float* add, float* dx, void* dx16, float* dgamma, float* dbeta, float* partials,
                                      int partial_rows, int rows, int D, float eps, hipStream_t s) {
     switch (D) {
-        case 256: return ln_bwd_launch<1>(x, x_row_stride, gamma, g, g_bf16, add, dx, dgamma, dbeta, partials, partial_rows, rows, eps, s);
-        case 512: return ln_bwd_launch<2>(x, x_row_stride, gamma, g, g_bf16, add, dx, dgamma, dbeta, partials, partial_rows, rows, eps, s);
-        case 768: return ln_bwd_launch<3>(x, x_row_stride, gamma, g, g_bf16, add, dx, dgamma, dbeta, partials, partial_rows, rows, eps, s);
-        case 1024: return ln_bwd_launch<4>(x, x_row_stride, gamma, g, g_bf16, add, dx, dgamma, dbeta, partials, partial_rows, rows, eps, s);
-        case 1280: return ln_bwd_launch<5>(x, x_row_stride, gamma, g, g_bf16, add, dx, dgamma, dbeta, partials, partial_rows, rows, eps, s);
+        case 256: return ln_bwd_launch<1>(x, x_row_stride, gamma, g, g_bf16, add, dx, dx16, dgamma, dbeta, partials, partial_rows, rows, eps, s);
+        case 512: return ln_bwd_launch<2>(x, x_row_stride, gamma, g, g_bf16, add, dx, dx16, dgamma, dbeta, partials, partial_rows, rows, eps, s);
+        case 768: return ln_bwd_launch<3>(x, x_row_stride, gamma, g, g_bf16, add, dx, dx16, dgamma, dbeta, partials, partial_rows, rows, eps, s);
+        case 1024: return ln_bwd_launch<4>(x, x_row_stride, gamma, g, g_bf16, add, dx, dx16, dgamma, dbeta, partials, partial_rows, rows, eps, s);
+        case 1280: return ln_bwd_launch<5>(x, x_row_stride, gamma, g, g_bf16, add, dx, dx16, dgamma, dbeta, partials, partial_rows, rows, eps, s);
         default: return hipErrorInvalidValue;
     }
 }

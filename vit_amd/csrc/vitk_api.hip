@@ -317,7 +317,7 @@ int vitk_target_rank(const float* logits, const int64_t* target, int* rank, int 
 }
 
 int vitk_layernorm_backward(const float* x, int64_t x_row_stride, const float* gamma, const void* g, int g_dtype,
-                            const float* add, float* dx, float* dgamma, float* dbeta, float* partials, int partial_rows, int rows,
+                            const float* add, float* dx, void* dx_bf16, float* dgamma, float* dbeta, float* partials, int partial_rows, int rows,
                             int D, float eps, void* stream) {
     if (!x || !gamma || !g || !dx || !dgamma || !dbeta || !partials)
         return fail(VITK_ERR_INVALID, "vitk_layernorm_backward: null pointer");
@@ -328,9 +328,9 @@ int vitk_layernorm_backward(const float* x, int64_t x_row_stride, const float* g
     if (D % 256 != 0 || D < 256 || D > 1280)
         return fail(VITK_ERR_UNSUPPORTED, "vitk_layernorm_backward: D=%d (supported: 256..1280 in steps of 256)", D);
     if (!aligned16(x) || !aligned16(gamma) || !aligned16(g) || !aligned16(dx) || !aligned16(partials) ||
-        (add && !aligned16(add)) || x_row_stride % 4 != 0 || x_row_stride < D)
+        (add && !aligned16(add)) || (dx_bf16 && !aligned16(dx_bf16)) || x_row_stride % 4 != 0 || x_row_stride < D)
         return fail(VITK_ERR_INVALID, "vitk_layernorm_backward: misaligned pointer or row stride");
-    return launched(launch_layernorm_backward(x, x_row_stride, gamma, g, g_dtype == VITK_BF16, add, dx, dgamma, dbeta, partials,
+    return launched(launch_layernorm_backward(x, x_row_stride, gamma, g, g_dtype == VITK_BF16, add, dx, dx_bf16, dgamma, dbeta, partials,
                                               partial_rows, rows, D, eps, reinterpret_cast<hipStream_t>(stream)),
                     "vitk_layernorm_backward");
 }

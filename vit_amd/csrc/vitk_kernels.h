@@ -45,7 +45,7 @@ hipError_t launch_cls_pos(const float* cls, const float* pos, float* x, int batc
 hipError_t launch_im2col(const void* img, void* cols, int batch, int img_h, int img_w, int patch, int kpad,
                          hipStream_t s);
 hipError_t launch_layernorm_backward(const float* x, int64_t x_row_stride, const float* gamma, const void* g,
-                                     bool g_bf16, const float* add, float* dx, float* dgamma, float* dbeta, float* partials,
+                                     bool g_bf16, const float* add, float* dx, void* dx16, float* dgamma, float* dbeta, float* partials,
                                      int partial_rows, int rows, int D, float eps, hipStream_t s);
 int gemm_tn_splits(int M, int N, int R);
 hipError_t launch_gemm_tn(const void* G, const void* X, float* C, float* part, int M, int N, int R, int ldg, int ldx,

@@ -41,7 +41,7 @@ SIGNATURES = {
     "vitk_attention_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "vitk_colsum_bf16": [_p, _p, _p, _i, _i, _i, _p],
     "vitk_gemm_tn": [_p, _p, _p, _p, _i64, _i, _i, _i, _p],
-    "vitk_layernorm_backward": [_p, _i64, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
+    "vitk_layernorm_backward": [_p, _i64, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
 }
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_TANH = 0, 1, 2, 3      # vitk_gemm_f32 epilogues (include/vitk.h)
 EXPORTS = sorted(list(SIGNATURES) + ["vitk_version", "vitk_last_error", "vitk_set_debug_variant",

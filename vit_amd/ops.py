@@ -305,9 +305,10 @@ def target_rank(logits, target, out=None):
 _ln_partials = {}
 
 
-def layernorm_backward(x, gamma, g, eps, add=None):
+def layernorm_backward(x, gamma, g, eps, add=None, dx_bf16=None):
     """(dx f32 [rows, D], dgamma f32 [D], dbeta f32 [D]) of y = LayerNorm(x) for the output gradient g
-    (bf16 or f32 [rows, D]); x f32 [rows, D] contiguous; add (f32 [rows, D], optional) is added to dx."""
+    (bf16 or f32 [rows, D]); x f32 [rows, D] contiguous; add (f32 [rows, D], optional) is added to dx;
+    dx_bf16 (bf16 [rows, D], optional) receives dx rounded to bf16."""
     L = _lib.load()
     _chk(x, torch.float32, "x")
     _chk(gamma, torch.float32, "gamma")
@@ -327,7 +328,7 @@ def layernorm_backward(x, gamma, g, eps, add=None):
     dbeta = torch.empty(D, dtype=torch.float32, device=x.device)
     gd = _lib.VITK_BF16 if g.dtype == torch.bfloat16 else _lib.VITK_F32
     with _span("layernorm_backward"):
-        _lib.check(L.vitk_layernorm_backward(_ptr(x), D, _ptr(gamma), _ptr(g), gd, _ptr(add), _ptr(dx), _ptr(dgamma), _ptr(dbeta),
+        _lib.check(L.vitk_layernorm_backward(_ptr(x), D, _ptr(gamma), _ptr(g), gd, _ptr(add), _ptr(dx), _ptr(dx_bf16), _ptr(dgamma), _ptr(dbeta),
                                              _ptr(part), part.shape[0], rows, D, float(eps), _stream()), L)
     return dx, dgamma, dbeta
 

@@ -11,8 +11,11 @@ reports the dominant kernel (the fc1 GEMM+bias+GELU launch) against the bf16 MFM
 with HIP events inside the timed region, and the CPU oracle timed on this box's host cores.
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,7 +29,22 @@ from vit_amd import dist as vdist               # noqa: E402
 from vit_amd import ops, synth                  # noqa: E402
 
 MFMA_BF16_PEAK = 2.5166e15     # dense bf16 FLOP/s per MI355X: 256 CU x 2.4 GHz x 4096 FLOP/clk/CU
-FC1_PMC_TRAFFIC = 2 * 182.0e3 * 1024 + 302.6e3 * 1024     # bytes: 2 x FETCH_SIZE KiB + WRITE_SIZE KiB of gemm_bf16_pp<1>
+
+
+def profiled_traffic(workload, kernel):
+    """HBM-side bytes per launch of `kernel` in `workload` from the newest profiles/rNN/traffic.json (written
+    by tools/pmc_summary.py from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes), or None when no profile of
+    this workload is committed.  Returns (bytes, file) so the JSON line names its source."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                table = json.load(f)
+        except (OSError, ValueError):
+            continue
+        entry = table.get(workload, {}).get(kernel)
+        if entry is not None:
+            return float(entry["hbm_bytes"]), os.path.relpath(path, ROOT)
+    return None, None
 
 
 def flops_per_image(cfg, img_size, num_classes=1000):
@@ -74,8 +92,66 @@ def cpu_baseline(arch, img_size, sd_cpu, batch):
         vo.forward(sd_cpu, x, cfg)
         ts.append(time.perf_counter() - t0)
     ts.sort()
+    # cores = the threads torch actually ran on (the box grants this job a CPU share smaller than the machine
+    # and sets OMP_NUM_THREADS to it); host_cpus = what the machine reports
     return {"value": round(batch / ts[1], 3), "unit": "images/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"{arch} {img_size}px fp32 forward, batch {batch}, median of 3 after warm-up"}
+            "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": f"{arch} {img_size}px fp32 forward, batch {batch}, median of 3 after warm-up"}
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` as ONE command: this parent starts N fresh child processes (one per GPU,
+    the reference's process model: run.py:121-124, utils.py:95-96) with the torch.distributed environment
+    set, forwards rank 0's JSON line and returns non-zero if any rank fails.  The parent never touches a
+    GPU (no torch.cuda call happens before this point), and nothing is exec'ed."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].stdout.read().decode()
+    rc = 0
+    deadline = time.time() + 600
+    for p in procs:
+        try:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+        rc = rc or p.returncode
+    for line in out0.splitlines():          # the JSON line to stdout, library chatter (gloo / RCCL banners) to stderr
+        print(line, file=sys.stdout if line.startswith("{") else sys.stderr, flush=True)
+    if rc != 0:
+        print(f"bench.py: a rank exited with status {rc}", file=sys.stderr)
+    return 1 if rc != 0 else 0
+
+
+def rehearse(a):
+    """Launcher / barrier / max-over-ranks / JSON plumbing with NO GPU work (CPU-only test boxes): the step is
+    a fixed host-side matmul.  The line it prints is labelled as a rehearsal and carries no throughput claim."""
+    rank, world, _ = vdist.init_from_env(backend="gloo")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    m = torch.ones(64, 64)
+    for _ in range(a.warmup):
+        m @ m
+    vdist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        m @ m
+    vdist.barrier()
+    dt = vdist.max_over_ranks(time.perf_counter() - t0)
+    if rank == 0:
+        print(json.dumps({"metric": "rehearsal: launcher and reduction plumbing only, no GPU work", "value": None,
+                          "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": round(dt / a.steps * 1e3, 4), "data": "none"}), flush=True)
+    if world > 1:
+        vdist.barrier()
+        torch.distributed.destroy_process_group()
 
 
 def main():
@@ -92,7 +168,14 @@ def main():
     ap.add_argument("--mode", default="fwd", choices=["fwd", "train"],
                     help="fwd: the headline forward benchmark; train: one training step per timed step "
                          "(forward, CrossEntropyLoss, backward, clip_grad_norm_ 1.0, AdamW; main.py:207-223 of the reference)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="exercise the multi-process launch and the timing reduction on CPU (gloo), no GPU work")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(a.gpus, sys.argv[1:]))
+    if a.rehearse:
+        return rehearse(a)
 
     # Rehearsal switches for a box with fewer GPUs than ranks (never set by the real launch): the ranks
     # then share GPU (local % count) and talk over gloo, since RCCL refuses two ranks on one device.
@@ -179,6 +262,7 @@ def main():
         D, Mh = cfg["hidden_size"], int(cfg["hidden_size"] * cfg["mlp_ratio"])
         k_flops = 2.0 * a.batch * ntok * Mh * D                  # one fc1 launch: [B*N, D] x [M, D]^T
         k_ms = timer.mean_ms()
+        traffic, traffic_src = profiled_traffic(f"{a.arch}_{a.img_size}_bs{a.batch}", "fc1")
         achieved = k_flops / (k_ms * 1e-3) / 1e12
         out = {
             "metric": f"images/sec (whole node) ViT-{a.arch.upper()[0]}/{cfg['patches']} {a.img_size}px {a.precision} "
@@ -199,9 +283,9 @@ def main():
                          "achieved": round(achieved, 1), "peak": round(MFMA_BF16_PEAK / 1e12, 1),
                          "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_BF16_PEAK, 4),
                          "avg_launch_ms": round(k_ms, 4), "launches": len(timer.pairs),
-                         # HBM-side bytes of one fc1 launch at the BASELINE shape from rocprofv3 PMC passes
-                         # (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, profiles/r01/pmc_summary.txt); not collected live
-                         "traffic": FC1_PMC_TRAFFIC if (a.arch, a.img_size, a.batch) == ("b16", 224, 256) else None},
+                         # HBM-side bytes of one fc1 launch from the committed rocprofv3 PMC passes of this
+                         # workload (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE); not collected live
+                         "traffic": traffic, "traffic_source": traffic_src},
         }
         if a.precision != "bf16":
             out.pop("roofline")          # the roofline entry describes the bf16 fc1 kernel only

@@ -41,23 +41,25 @@ int vitk_version(void);
 /* Message for the last non-zero return on the calling thread ("" if none). */
 const char* vitk_last_error(void);
 
-/* Test and measurement hook: choose an alternative implementation of the tiled GEMM and of attention.
+/* Test and measurement hook (state of the CALLING THREAD, default 0 = production kernels): choose an
+ * alternative implementation of the tiled GEMM and of attention.
  * gemm_variant, low 4 bits: 0 (and 4) = default (two-group phased kernel where K/64 is even and A is a
  *   plain matrix, else the one-group pipelined kernel), 1 = basic kernel with LDS-DMA staging, 2 = force
  *   the small untiled kernel, 3 = basic kernel with register staging, 5 = one-group pipelined kernel.
  *   gemm_variant >> 4 (= "order"): bits 0-3 tile order (1 = no n-grouping, 3 = group width from bits
  *   4-7), bits 8-12 force the tile height (in 16-row units).
- *   Timing probes, which produce WRONG OR NO RESULTS: order bits 17-19 on the bias -> bf16 epilogue of
- *   the default kernel (1 = no DMA, 2 = no epilogue, 3 = accumulator clearing instead of the zero C
- *   operand, 7 = cycle stamps written over out[0..]), order bit 22 = bf16 epilogues without stores.
+ *   Timing probes (WRONG OR NO RESULTS) exist only in diagnostic builds of the library (-DVITK_PROBES,
+ *   `python -m vit_amd.build --probes` -> libvitk_probes.so), never in libvitk.so: order bits 17-19 on the
+ *   bias -> bf16 epilogue of the default kernel (1 = no DMA, 2 = no epilogue, 3 = accumulator clearing
+ *   instead of the zero C operand, 7 = cycle stamps written over out[0..]), order bit 22 = bf16 epilogues
+ *   without stores.
  * attention_variant, low 2 bits: 0 = automatic (persistent workgroups that hold two heads' K/V in LDS and
  *   stage the next head under the current one's key loop when two heads fit: ntok <= 256 at head_dim 64,
  *   160 at 80 / 96; one head per workgroup when one fits: ntok <= 608 / 288; else streamed), 1 = one head
  *   per workgroup with V stored transposed (head_dim 64), 2 = K/V streamed through LDS in 64-key chunks,
- *   3 = one head per workgroup; timing probes (WRONG OR NO RESULTS): bit 2 = K/V of head 0 for every
- *   head, bit 3 = no key loop, bit 4 = no output stores.
- * Process-global; apart from the probes, results are identical across variants up to fp32 summation
- * order. */
+ *   3 = one head per workgroup; diagnostic builds only: bit 2 = K/V of head 0 for every head, bit 3 = no
+ *   key loop, bit 4 = no output stores.
+ * Results are identical across variants up to fp32 summation order. */
 void vitk_set_debug_variant(int gemm_variant, int attention_variant);
 
 /* y[r, :] = LayerNorm(x[r, :]) * gamma + beta over D columns, fp32 statistics.
@@ -218,6 +220,21 @@ int vitk_gemm_bias_gelu_dual(const void* A, const void* W, const float* bias, vo
  * [R, M] contiguous, M a multiple of 256.  partials: caller's scratch, f32 [partial_rows, M]; up to
  * min(partial_rows, 256) row chunks are summed separately and added in a fixed order. */
 int vitk_colsum_bf16(const void* G, float* out, float* partials, int partial_rows, int R, int M, void* stream);
+
+/* ---- for callers that cannot allocate ------------------------------------------------------------- */
+
+/* Optional set-up for the current device: resolves the library's built-in scratch (used by
+ * vitk_colsum_bf16_static) so that the first real call does no look-up.  Allocates nothing. */
+int vitk_init(void);
+
+/* vitk_colsum_bf16 without a workspace argument and without any allocation: the partial sums go to a 4 MiB
+ * buffer built into the library's device code (one per GPU, held until the process ends).  It has no
+ * counterpart in the reference; it exists for callers that cannot call hipMalloc or bring a workspace: code
+ * under HIP graph capture, tight serving loops, harnesses that forbid allocation.  M a multiple of 256 and
+ * <= 4096 (larger M: VITK_ERR_UNSUPPORTED).  Same kernels and summation order as vitk_colsum_bf16 with
+ * partial_rows = 256, so the results are bit-identical.  All calls on one GPU share the buffer: calls that
+ * overlap on one GPU (different streams) race; calls on one stream are ordered and safe. */
+int vitk_colsum_bf16_static(const void* G, float* out, int R, int M, void* stream);
 
 #ifdef __cplusplus
 }

@@ -34,9 +34,13 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    """Compile every .hip source to an object (in parallel) and link libvitk.so."""
-    objdir = os.path.join(HERE, "build")
+def build(force=False, verbose=True, probes=False):
+    """Compile every .hip source to an object (in parallel) and link libvitk.so.  probes=True builds the
+    diagnostic library libvitk_probes.so instead (-DVITK_PROBES: timing probes that give wrong or no results,
+    for tools/ only; select it with VITK_LIB=...)."""
+    objdir = os.path.join(HERE, "build_probes" if probes else "build")
+    lib = os.path.join(HERE, "libvitk_probes.so") if probes else LIB
+    flags = FLAGS + (["-DVITK_PROBES"] if probes else [])
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     jobs = []
@@ -48,7 +52,7 @@ def build(force=False, verbose=True):
 
     def compile_one(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        cmd = [hipcc] + flags + ["-c", s, "-o", o]
         if verbose:
             print("[vit_amd.build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
@@ -57,14 +61,13 @@ def build(force=False, verbose=True):
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(compile_one, jobs))
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
-    if force or jobs or _stale(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
+    if force or jobs or _stale(lib, objs):
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", lib] + objs
         if verbose:
             print("[vit_amd.build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    print(build(force="--force" in sys.argv, probes="--probes" in sys.argv))

@@ -29,7 +29,13 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
 
 constexpr float kMaskedScore = -1.0e30f;
-static int g_attn_probe = 0;   // timing probes (debug variant bits 2..4): K/V of head 0, no key loop, no stores
+// Timing probes (K/V of head 0 for every head, no key loop, no stores: wrong or no results) exist in
+// diagnostic builds only; elsewhere the kernel's `probe` argument is ignored and the checks fold away.
+#ifdef VITK_PROBES
+#define VITK_ATTN_PROBE(p) (p)
+#else
+#define VITK_ATTN_PROBE(p) 0
+#endif
 
 // VTR = true : V row-major in LDS, transposed fragments via ds_read_b64_tr_b16.
 // VTR = false: V stored transposed ([d][key]) in LDS, fragments via ds_read_b64.
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
     // are masked out of the softmax, and their P is 0 in P.V); at head_dim 96 the slots whose chunk would
     // be 12..15 re-read chunk 11 and are never read back.
     auto stage = [&](char* dst, int row0, int pieces, int head) {
-        if (probe & 1) head = 0;                            // timing probe: K/V from one head (cache-resident)
+        if (VITK_ATTN_PROBE(probe) & 1) head = 0;                            // timing probe: K/V from one head (cache-resident)
         const bf16_t* kg = K + (size_t)head * ntok * HD;
         const bf16_t* vg = V + (size_t)head * ntok * HD;
         for (int pi = wave; pi < 2 * pieces; pi += NW) {     // wave-uniform
@@ -325,7 +331,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
     };
     using C1 = std::integral_constant<int, 1>;
     using C2 = std::integral_constant<int, 2>;
-    const int kend = (probe & 2) ? 0 : kblocks;      // probe bit 1: skip the key loop (timing only)
+    const int kend = (VITK_ATTN_PROBE(probe) & 2) ? 0 : kblocks;      // probe bit 1: skip the key loop (timing only)
 
     // normalise and store one q-tile: lane holds q = qrow, d = 32*blk + 8g + 4*hh + (0..3)
     auto finish = [&]() {
@@ -350,7 +356,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
                     *reinterpret_cast<u32x2*>(win + r * 128 + (((d * 4 + g) ^ (r & 7)) << 4) + ((hh ^ ((r >> 3) & 1)) << 3)) = pk;
                 }
             const int rc = lane >> 3, cc = lane & 7;
-            if (!(probe & 4)) {                                  // probe bit 2: no output stores (timing only)
+            if (!(VITK_ATTN_PROBE(probe) & 4)) {                                  // probe bit 2: no output stores (timing only)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = i * 8 + rc;
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
                         *reinterpret_cast<u32x4*>(O + (((size_t)b * ntok + q0 + row) * heads + h) * HD + cc * 8) = v;
                 }
             }
-        } else if (qrow < ntok && !(probe & 4)) {
+        } else if (qrow < ntok && !(VITK_ATTN_PROBE(probe) & 4)) {
             bf16_t* og = O + (((size_t)b * ntok + qrow) * heads + h) * HD + 4 * hh;
 #pragma unroll
             for (int d = 0; d < DB; ++d)
@@ -457,7 +463,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
 
 template <int HD, int NW, bool VTR, bool STREAM, bool PD = false>
 static hipError_t attn_launch(const void* q, const void* k, const void* v, void* out, int batch, int heads,
-                              int ntok, float scale, hipStream_t s, float* lse) {
+                              int ntok, float scale, hipStream_t s, float* lse, int probe) {
     const int kpad = ((ntok + 31) / 32) * 32;
     const int rb = HD == 64 ? 128 : 256;
     const size_t lds = STREAM ? (size_t)4 * 64 * rb
@@ -475,7 +481,7 @@ static hipError_t attn_launch(const void* q, const void* k, const void* v, void*
     hipLaunchKernelGGL((attention_fwd<HD, NW, VTR, STREAM, PD>), grid, block, lds, s,
                        reinterpret_cast<const bf16_t*>(q), reinterpret_cast<const bf16_t*>(k),
                        reinterpret_cast<const bf16_t*>(v), reinterpret_cast<bf16_t*>(out), ntok, heads,
-                       scale * 1.44269504088896340736f, g_attn_probe, nbh, lse);
+                       scale * 1.44269504088896340736f, probe, nbh, lse);
     return hipGetLastError();
 }
 
@@ -496,7 +502,7 @@ hipError_t launch_attention(const void* q, const void* k, const void* v, void* o
     if ((mode == 1 && (hd != 64 || !fits)) || (mode == 3 && !fits)) return hipErrorInvalidValue;
     if (mode == 0 && !fits) mode = 2;
     if (mode == 0 && !fits2) mode = 3;
-    g_attn_probe = (variant >> 2) & 7;
+    const int probe = (variant >> 2) & 7;       // read by diagnostic builds only
     // Waves per workgroup (one 32-row q-tile at a time each).  Resident K/V: one workgroup per head, its
     // waves take q-tiles round-robin; the width with the best balance (q-tiles / (rounds * waves)), the
     // larger on ties.  Streamed: one q-tile per wave, fewest workgroups per head, then fewest idle slots.
@@ -519,16 +525,16 @@ hipError_t launch_attention(const void* q, const void* k, const void* v, void* o
     }
 #define VITK_ATTN_CASE(NWV)                                                                                   \
     case NWV:                                                                                                 \
-        if (hd == 96 && mode == 2) return attn_launch<96, NWV, true, true>(q, k, v, out, batch, heads, ntok, scale, s, lse);  \
-        if (hd == 96 && mode == 0) return attn_launch<96, NWV, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s, lse);  \
-        if (hd == 96) return attn_launch<96, NWV, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse);   \
-        if (hd == 80 && mode == 2) return attn_launch<80, NWV, true, true>(q, k, v, out, batch, heads, ntok, scale, s, lse);  \
-        if (hd == 80 && mode == 0) return attn_launch<80, NWV, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s, lse);  \
-        if (hd == 80) return attn_launch<80, NWV, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse);   \
-        if (mode == 2) return attn_launch<64, NWV, true, true>(q, k, v, out, batch, heads, ntok, scale, s, lse);   \
-        if (mode == 0) return attn_launch<64, NWV, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s, lse);  \
-        if (mode == 3) return attn_launch<64, NWV, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse);  \
-        return attn_launch<64, NWV, false, false>(q, k, v, out, batch, heads, ntok, scale, s, lse);
+        if (hd == 96 && mode == 2) return attn_launch<96, NWV, true, true>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);  \
+        if (hd == 96 && mode == 0) return attn_launch<96, NWV, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);  \
+        if (hd == 96) return attn_launch<96, NWV, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);   \
+        if (hd == 80 && mode == 2) return attn_launch<80, NWV, true, true>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);  \
+        if (hd == 80 && mode == 0) return attn_launch<80, NWV, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);  \
+        if (hd == 80) return attn_launch<80, NWV, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);   \
+        if (mode == 2) return attn_launch<64, NWV, true, true>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);   \
+        if (mode == 0) return attn_launch<64, NWV, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);  \
+        if (mode == 3) return attn_launch<64, NWV, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);  \
+        return attn_launch<64, NWV, false, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);
     switch (nw) {
         VITK_ATTN_CASE(4)
         VITK_ATTN_CASE(5)
@@ -537,11 +543,11 @@ hipError_t launch_attention(const void* q, const void* k, const void* v, void* o
         VITK_ATTN_CASE(8)
         case 10:      // resident modes only
             // (head_dim 80 / 96 with two resident heads has at most 5 q-tiles: never 10 waves)
-            if (hd == 96) return attn_launch<96, 10, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse);
-            if (hd == 80) return attn_launch<80, 10, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse);
-            if (mode == 0) return attn_launch<64, 10, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s, lse);
-            if (mode == 3) return attn_launch<64, 10, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse);
-            return attn_launch<64, 10, false, false>(q, k, v, out, batch, heads, ntok, scale, s, lse);
+            if (hd == 96) return attn_launch<96, 10, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);
+            if (hd == 80) return attn_launch<80, 10, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);
+            if (mode == 0) return attn_launch<64, 10, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);
+            if (mode == 3) return attn_launch<64, 10, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);
+            return attn_launch<64, 10, false, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);
     }
 #undef VITK_ATTN_CASE
     return hipErrorInvalidValue;

@@ -1,5 +1,7 @@
 // Backward kernels of the training step (gfx950 / CDNA4).  Bandwidth-bound row work only so far: the
 // GEMM and attention gradients still come from library calls on the host side.
+#include <mutex>
+
 #include "vitk_common.h"
 #include "vitk_kernels.h"
 
@@ -231,6 +233,33 @@ hipError_t launch_colsum_bf16(const void* G, float* out, float* partials, int pa
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(reduce_partial_rows, dim3(M / 64), dim3(1024), 0, s, partials, chunks, M, out);
     return hipGetLastError();
+}
+
+// Partial sums of vitk_colsum_bf16_static: 4 MiB of device memory that belongs to the library's code object,
+// one copy per GPU the library runs on, for the life of the process.  Host code never uses the symbol as
+// an address: the device address is looked up once per device and that pointer goes to the kernels.
+// Every call on a device shares the buffer; each call overwrites the partial rows it then reads, so nothing
+// has to be cleared, but two calls that overlap on one device (different streams) race.
+static __device__ __align__(256) float scratch[kColsumStaticRows * kColsumStaticMaxM];
+
+hipError_t colsum_static_scratch(float** out) {
+    constexpr int kMaxDevices = 64;
+    static std::mutex mu;
+    static float* ptrs[kMaxDevices] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ptrs[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        ptrs[dev] = static_cast<float*>(p);
+    }
+    if (out) *out = ptrs[dev];
+    return hipSuccess;
 }
 
 }  // namespace vitk

@@ -118,8 +118,10 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
                 } else {
                     off = (uint32_t)(mw + lr) * p.ldo + col_off;
                 }
-                if ((!MASKED || lr < row_limit) && !((p.order >> 22) & 1))      // debug bit 22: no stores (timing probe)
-                    *reinterpret_cast<u32x4*>(dst + off * 2u) = v;
+#ifdef VITK_PROBES
+                if ((p.order >> 22) & 1) continue;                // diagnostic builds: order bit 22 = no stores (timing probe)
+#endif
+                if (!MASKED || lr < row_limit) *reinterpret_cast<u32x4*>(dst + off * 2u) = v;
             }
             }
         }

@@ -387,7 +387,8 @@ static hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
     const PipePlan pl = make_plan(b, cus);
     const int tiles = pl.tiles_m * pl.tiles_n;
     const int grid = tiles < cus ? tiles : cus;
-    const int probe = (b.order >> 17) & 7;           // debug: bits 17..19 select a timing probe (plain bf16 epilogue only)
+#ifdef VITK_PROBES                                   // timing probes (wrong or no results): diagnostic builds only
+    const int probe = (b.order >> 17) & 7;           // bits 17..19 select a timing probe (plain bf16 epilogue only)
     if constexpr (EPI == EPI_BIAS_BF16) {
         if (probe == 1) hipLaunchKernelGGL((gemm_bf16_pp<EPI, 1>), dim3(grid), dim3(kGemmThreads), 0, s, b, pl);
         if (probe == 7) hipLaunchKernelGGL((gemm_bf16_pp<EPI, 7>), dim3(grid), dim3(kGemmThreads), 0, s, b, pl);
@@ -395,6 +396,7 @@ static hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
         if (probe == 3) hipLaunchKernelGGL((gemm_bf16_pp<EPI, 3>), dim3(grid), dim3(kGemmThreads), 0, s, b, pl);
         if (probe == 1 || probe == 2 || probe == 3 || probe == 7) return hipGetLastError();
     }
+#endif
     hipLaunchKernelGGL((gemm_bf16_pp<EPI>), dim3(grid), dim3(kGemmThreads), 0, s, b, pl);
     return hipGetLastError();
 }

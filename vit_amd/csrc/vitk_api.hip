@@ -12,8 +12,8 @@ using namespace vitk;
 namespace {
 
 thread_local char g_err[256] = "";
-int g_gemm_variant = 0;
-int g_attn_variant = 0;
+thread_local int g_gemm_variant = 0;      // test hook (vitk_set_debug_variant): per calling thread, default 0
+thread_local int g_attn_variant = 0;
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -61,7 +61,7 @@ int dense(const char* name, const void* A, const void* W, const float* bias, con
 
 extern "C" {
 
-int vitk_version(void) { return 2; }
+int vitk_version(void) { return 3; }
 
 const char* vitk_last_error(void) { return g_err; }
 
@@ -382,6 +382,25 @@ int vitk_colsum_bf16(const void* G, float* out, float* partials, int partial_row
         return fail(VITK_ERR_INVALID, "vitk_colsum_bf16: pointers must be 16-byte aligned");
     return launched(launch_colsum_bf16(G, out, partials, partial_rows, R, M, reinterpret_cast<hipStream_t>(stream)),
                     "vitk_colsum_bf16");
+}
+
+int vitk_init(void) {
+    return launched(colsum_static_scratch(nullptr), "vitk_init");
+}
+
+int vitk_colsum_bf16_static(const void* G, float* out, int R, int M, void* stream) {
+    if (!G || !out) return fail(VITK_ERR_INVALID, "vitk_colsum_bf16_static: null pointer");
+    if (R <= 0 || M <= 0) return fail(VITK_ERR_INVALID, "vitk_colsum_bf16_static: non-positive size");
+    if (M % 256 != 0) return fail(VITK_ERR_UNSUPPORTED, "vitk_colsum_bf16_static: M=%d is not a multiple of 256", M);
+    if (M > kColsumStaticMaxM)
+        return fail(VITK_ERR_UNSUPPORTED, "vitk_colsum_bf16_static: M=%d exceeds the built-in scratch (M <= %d); use vitk_colsum_bf16 with a caller workspace",
+                    M, kColsumStaticMaxM);
+    if (!aligned16(G) || !aligned16(out)) return fail(VITK_ERR_INVALID, "vitk_colsum_bf16_static: pointers must be 16-byte aligned");
+    float* scratch = nullptr;
+    hipError_t e = colsum_static_scratch(&scratch);
+    if (e != hipSuccess) return launched(e, "vitk_colsum_bf16_static(scratch)");
+    return launched(launch_colsum_bf16(G, out, scratch, kColsumStaticRows, R, M, reinterpret_cast<hipStream_t>(stream)),
+                    "vitk_colsum_bf16_static");
 }
 
 }  // extern "C"

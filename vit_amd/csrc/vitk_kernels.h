@@ -51,6 +51,10 @@ int gemm_tn_splits(int M, int N, int R);
 hipError_t launch_gemm_tn(const void* G, const void* X, float* C, float* part, int M, int N, int R, int ldg, int ldx,
                           hipStream_t s);
 hipError_t launch_colsum_bf16(const void* G, float* out, float* partials, int partial_rows, int R, int M, hipStream_t s);
+// the library's own partial-sum buffer for vitk_colsum_bf16_static: f32 [kColsumStaticRows, kColsumStaticMaxM]
+// in device memory of the current device (resolved once per device); out may be nullptr (resolve only)
+constexpr int kColsumStaticRows = 256, kColsumStaticMaxM = 4096;
+hipError_t colsum_static_scratch(float** out);
 hipError_t launch_normalize_u8(const void* in, void* out, int64_t n, int64_t plane, const float* mean,
                                const float* std, bool out_bf16, hipStream_t s);
 hipError_t launch_target_rank(const float* logits, const int64_t* target, int* rank, int rows, int classes,

@@ -430,3 +430,19 @@ def colsum(g):
     with _span("colsum"):
         _lib.check(L.vitk_colsum_bf16(_ptr(g), _ptr(out), _ptr(part), 256, R, M, _stream()), L)
     return out
+
+
+def colsum_static(g, out=None):
+    """colsum() through vitk_colsum_bf16_static: the partial sums live in the library's built-in device
+    buffer, so the call allocates nothing when `out` is given (M <= 4096)."""
+    L = _lib.load()
+    _chk(g, torch.bfloat16, "g")
+    R, M = g.shape
+    if out is None:
+        out = torch.empty(M, dtype=torch.float32, device=g.device)
+    _chk(out, torch.float32, "out")
+    if out.numel() != M:
+        raise _lib.VitkError(f"colsum_static: out has {out.numel()} elements, expected {M}")
+    with torch.cuda.device(g.device), _span("colsum"):
+        _lib.check(L.vitk_colsum_bf16_static(_ptr(g), _ptr(out), R, M, _stream()), L)
+    return out

@@ -216,6 +216,19 @@ int vitk_attention_backward(const void* q, const void* k, const void* v, const v
 int vitk_gemm_bias_gelu_dual(const void* A, const void* W, const float* bias, void* pre, void* out, int M, int N, int K,
                              void* stream);
 
+/* Input gradient of a Linear layer whose output went through an activation, in the training step (autograd of
+ * models/transformer.py:21-24 and models/vision_transformer.py:53-54):
+ *   out bf16 [M,N] = bf16(G Wt^T) * f'(aux)
+ * G bf16 [M,K] = the gradient arriving at the NEXT layer's output, Wt bf16 [N,K] = that layer's weight transposed
+ * (so G Wt^T = G W, the gradient of the next layer's input = this activation's output), aux bf16 [M,N]:
+ * act = VITK_ACT_GELU: aux is the pre-activation (vitk_gemm_bias_gelu_dual's `pre`), f' = exact-erf GELU';
+ * act = VITK_ACT_TANH: aux is the tanh OUTPUT, f' = 1 - aux^2.  K % 32 == 0.
+ * Input gradients without an activation are vitk_gemm_bias(G, Wt, NULL, ...). */
+#define VITK_ACT_GELU 0
+#define VITK_ACT_TANH 1
+int vitk_gemm_grad_act(const void* G, const void* Wt, const void* aux, void* out, int M, int N, int K, int act,
+                       void* stream);
+
 /* Bias gradient of a Linear layer in the training step: out[m] = sum_r G[r][m] with f32 accumulation; G bf16
  * [R, M] contiguous, M a multiple of 256.  partials: caller's scratch, f32 [partial_rows, M]; up to
  * min(partial_rows, 256) row chunks are summed separately and added in a fixed order. */

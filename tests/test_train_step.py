@@ -221,3 +221,55 @@ def test_gpu_bias_gradient_column_sum(R, M):
     want = g.double().sum(0)
     assert (got.double() - want).abs().max() <= 1e-5 * max(1.0, R ** 0.5) * 4
     assert torch.equal(got, ops.colsum(g))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(256, 768, 1024), (50432, 3072, 768), (50432, 768, 2304), (300, 512, 192), (100, 320, 96)])
+@pytest.mark.parametrize("act", ["gelu", "tanh"])
+def test_gpu_input_gradient_gemm_with_activation_derivative(M, N, K, act):
+    """vitk_gemm_grad_act: bf16(g Wt^T) * f'(aux) against fp64 on the same bf16 operands (GELU' by exact erf,
+    tanh' from the saved output), over the two-group kernel (K/64 even), the one-group kernel (K/64 odd) and
+    the untiled kernel (M < 128 or N not a multiple of 256)."""
+    from vit_amd import lib, ops
+    gen = torch.Generator().manual_seed(M + N + K)
+    g = torch.randn(M, K, generator=gen).to(torch.bfloat16).cuda()
+    wt = (torch.randn(N, K, generator=gen) * 0.05).to(torch.bfloat16).cuda()
+    aux = (torch.randn(M, N, generator=gen) * (1.5 if act == "gelu" else 0.6)).clamp(-0.99 if act == "tanh" else -9, 0.99 if act == "tanh" else 9)
+    aux = aux.to(torch.bfloat16).cuda()
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    ops.gemm_grad_act(g, wt, aux, out, lib.ACT_GELU if act == "gelu" else lib.ACT_TANH)
+    prod = (g.double() @ wt.double().t()).to(torch.bfloat16).double()      # a bf16 matmul's output
+    a = aux.double()
+    if act == "gelu":
+        d = 0.5 * (1 + torch.erf(a / 2 ** 0.5)) + a * torch.exp(-a * a / 2) / (2 * torch.pi) ** 0.5
+    else:
+        d = 1 - a * a
+    want = prod * d
+    err = (out.double() - want).abs()
+    # one bf16 rounding of the result, the product's own rounding boundary, and 2e-6 for the erf approximation
+    tol = want.abs() * 2 ** -7 + prod.abs() * 2 ** -7 * d.abs() + 1e-5
+    assert bool((err <= tol).all()), f"max excess {(err - tol).max():.3e}"
+    assert torch.isfinite(out).all()
+
+
+@pytest.mark.gpu
+def test_gpu_no_library_gemm_or_aten_gelu_backward_on_the_bf16_training_path():
+    """One bf16 step of a 64-row-aligned configuration under the profiler: every GEMM of the backward is a
+    libvitk kernel (no hipBLASLt / rocBLAS `Cijk_` kernel, no aten gelu_backward, no fused-attention backward)."""
+    import vit_amd
+    from torch.profiler import ProfilerActivity, profile
+    m = vit_amd.VisionTransformer(img_size=128, patches=16, num_classes=1000, hidden_size=256, num_layers=2, num_heads=4,
+                                  norm=lambda d: torch.nn.LayerNorm(d, eps=1e-6)).cuda().train()
+    x = torch.randn(64, 3, 128, 128, device="cuda")                        # 64 images x 65 tokens: rows % 64 == 0
+    t = torch.randint(0, 1000, (64,), device="cuda")
+    crit = torch.nn.CrossEntropyLoss()
+    crit(m(x), t).backward()
+    m.zero_grad()
+    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+        crit(m(x), t).backward()
+        torch.cuda.synchronize()
+    names = [e.key for e in prof.key_averages()]
+    bad = [n for n in names if "Cijk" in n or "gelu_backward" in n.lower() or "GeluBackward" in n
+           or "attention_backward" in n.lower() and "vitk" not in n.lower() or n.startswith("aten::mm") or n.startswith("aten::matmul")]
+    assert not bad, bad
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())

@@ -5,8 +5,11 @@ target); loss.backward(); clip_grad_norm_; optimizer.step()`).  Here every forwa
 kernel; each Function keeps what its backward needs and computes the gradients with torch operations on
 the GPU (library GEMMs, aten backward ops), recomputing cheap intermediates instead of storing them.
 Gradients arrive at the module's ordinary fp32 Parameters, so optimizers, `clip_grad_norm_` and
-DistributedDataParallel work unchanged.  Hand-written backward kernels so far: LayerNorm, the weight-gradient
-GEMM (dW = dY^T X) and attention.
+DistributedDataParallel work unchanged.  In the bf16 mode every gradient of the blocks comes from a libvitk
+kernel: LayerNorm backward, the weight-gradient GEMM (dW = dY^T X), bias column sums, attention backward, and
+the input gradients dX = dY W through the forward GEMM kernel on the transposed weight, with GELU' / tanh' in
+its epilogue.  torch operations remain for the fp32 mode, for shapes the kernels do not take (rows that do not
+fill 64-row tiles, head sizes other than 64) and for casts, slices and small reductions.
 
 cd = compute dtype of the GEMM operands: torch.bfloat16, or torch.float32 in the fp32 mode.
 """
@@ -14,7 +17,7 @@ import torch
 import torch.nn.functional as F
 
 from . import ops
-from .lib import EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_TANH, VitkError
+from .lib import ACT_GELU, ACT_TANH, EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_TANH, VitkError
 
 
 def _vjp(fn, inputs, grad_out):
@@ -25,17 +28,65 @@ def _vjp(fn, inputs, grad_out):
         return torch.autograd.grad(out, ins, grad_out)
 
 
-_handoff = [None]      # (f32 gradient, its bf16 copy) of the most recent LayerNorm backward
+def _operand(g, cd):
+    return g if g.dtype == cd else g.to(cd)
 
 
-def _as_operand(g, cd):
-    """g in the GEMM operand dtype: the copy the LayerNorm backward kernel already made, if g is that gradient."""
-    h = _handoff[0]
-    _handoff[0] = None
-    if h is not None and cd == torch.bfloat16 and h[0].data_ptr() == g.data_ptr() and h[0].shape == g.shape \
-            and g.dtype == torch.float32 and g.is_contiguous():
-        return h[1]
-    return g.to(cd)
+def _weight_grad(g, a):
+    """f32 [out, in] = g^T a for g [rows, out], a [rows, in]: the HIP split-k kernel on the rows that fill whole
+    64-row K tiles (bf16, out and in multiples of 256), a small library product for the remainder."""
+    g, a = g.contiguous(), a.contiguous()
+    rows = g.shape[0]
+    r64 = rows - rows % 64
+    if g.dtype == torch.bfloat16 and r64 > 0 and ops.gemm_tn_supported(g.shape[1], a.shape[1], r64):
+        gw = ops.gemm_tn(g[:r64], a[:r64])
+        if r64 < rows:
+            gw += (g[r64:].t() @ a[r64:]).float()
+        return gw
+    return (g.t() @ a).float()
+
+
+def _bias_grad(g, bias):
+    if bias is None:
+        return None
+    if g.dtype == torch.bfloat16 and g.shape[1] % 256 == 0:
+        return ops.colsum(g.contiguous()).to(bias.dtype)
+    return g.sum(0, dtype=torch.float32).to(bias.dtype)
+
+
+def _input_grad(g, w_cd, wt, aux=None, act=None):
+    """Gradient of a Linear layer's input, g W, for g [rows, out] in cd; with `aux` also through the activation
+    that produced that input: (g W) * f'(aux).  bf16 with the transposed weight at hand: the forward GEMM kernel
+    on (g, W^T), the activation's derivative in its epilogue; else torch."""
+    rows = g.shape[0]
+    if g.dtype == torch.bfloat16 and wt is not None and g.shape[1] == wt.shape[1] and g.shape[1] % 32 == 0:
+        out = torch.empty(rows, wt.shape[0], dtype=torch.bfloat16, device=g.device)
+        if aux is None:
+            return ops.gemm_bias(g.contiguous(), wt, None, out)
+        return ops.gemm_grad_act(g.contiguous(), wt, aux, out, act)
+    ga = g[:, :w_cd.shape[0]] @ w_cd
+    if aux is None:
+        return ga
+    if act == ACT_GELU:
+        return torch.ops.aten.gelu_backward(ga, aux)
+    o = aux.float()
+    return (ga.float() * (1.0 - o * o)).to(g.dtype)
+
+
+def _linear_backward(g_pre, a, w_cd, wt, weight, bias, aux=None, act=None):
+    """g_pre [rows, out] in cd -> (grad of a [rows, in] in cd (through `act` if given), grad weight, grad bias)."""
+    ga = _input_grad(g_pre, w_cd, wt, aux, act)
+    gw = _weight_grad(g_pre, a).to(weight.dtype)
+    return ga, gw, _bias_grad(g_pre, bias)
+
+
+def _ln_backward(x, weight, bias, eps, g, g_skip, want16):
+    """LayerNorm backward kernel: (dx f32, dx as bf16 or None, dgamma, dbeta); g_skip (the gradient that reaches
+    x along the residual branch) is added inside the kernel."""
+    add = None if g_skip is None else g_skip.contiguous()
+    gx16 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want16 else None
+    gx, gw, gb = ops.layernorm_backward(x, weight.detach(), g.contiguous(), eps, add=add, dx_bf16=gx16)
+    return gx, gx16, gw.to(weight.dtype), gb.to(bias.dtype)
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -59,117 +110,154 @@ class LayerNormFn(torch.autograd.Function):
         x, weight, bias = ctx.saved_tensors
         if g is None:                                                     # only the skip output was used
             return g_skip, None, None, None, None
-        add = None if g_skip is None else g_skip.contiguous()
-        gx16 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if g.dtype == torch.bfloat16 else None
-        gx, gw, gb = ops.layernorm_backward(x, weight.detach(), g.contiguous(), ctx.eps, add=add, dx_bf16=gx16)
-        # The Linear layer that produced x needs this gradient as a bf16 GEMM operand next: the kernel wrote that
-        # copy in the same pass.  Handed over out of band (autograd carries one tensor per edge); holding gx keeps
-        # its storage from being reused, so the pointer comparison at the consumer cannot match another tensor.
-        _handoff[0] = (gx, gx16) if gx16 is not None else None
-        return gx, gw.to(weight.dtype), gb.to(bias.dtype), None, None
+        gx, _, gw, gb = _ln_backward(x, weight, bias, ctx.eps, g, g_skip, False)
+        return gx, gw, gb, None, None
 
 
-def _weight_grad(g, a):
-    """f32 [out, in] = g^T a for g [rows, out], a [rows, in]: the HIP split-k kernel on the rows that fill whole
-    64-row K tiles (bf16, out and in multiples of 256), a small library product for the remainder."""
-    g, a = g.contiguous(), a.contiguous()
-    rows = g.shape[0]
-    r64 = rows - rows % 64
-    if g.dtype == torch.bfloat16 and r64 > 0 and ops.gemm_tn_supported(g.shape[1], a.shape[1], r64):
-        gw = ops.gemm_tn(g[:r64], a[:r64])
-        if r64 < rows:
-            gw += (g[r64:].t() @ a[r64:]).float()
-        return gw
-    return (g.t() @ a).float()
+class ResidualBranchFn(torch.autograd.Function):
+    """One residual branch's tail and the LayerNorm that follows it (models/transformer.py:69-76):
 
+        attention branch:  x' = x + ctx W_out^T + b                      (a = ctx, w1 = None)
+        MLP branch:        x' = x + gelu(a W_1^T + b_1) W_2^T + b_2      (a = LN2 output)
+        then               y  = LayerNorm_next(x')                       (ln_w = None: no LayerNorm, the last block)
 
-def _linear_backward(g_pre, a, w_cd, weight, bias):
-    """g_pre [rows, out] in cd -> (grad a [rows, in] in cd, grad weight f32, grad bias f32)."""
-    ga = g_pre @ w_cd
-    gw = _weight_grad(g_pre, a).to(weight.dtype)
-    if bias is None:
-        gb = None
-    elif g_pre.dtype == torch.bfloat16 and g_pre.shape[1] % 256 == 0:
-        gb = ops.colsum(g_pre.contiguous()).to(bias.dtype)
-    else:
-        gb = g_pre.sum(0, dtype=torch.float32).to(bias.dtype)
-    return ga, gw, gb
-
-
-class LinearFn(torch.autograd.Function):
-    """out = epilogue(a W^T + b).  kind: 'bias' (cd out), 'gelu' (cd), 'tanh' (cd), 'logits' (f32 out),
-    'resid' (f32 out = resid + a W^T + b).  w_cd is the kernel-ready copy of `weight` in cd."""
+    Returns (y, x') (or x' alone).  One Function so that the backward is one chain with explicit tensors: the
+    LayerNorm backward kernel writes the gradient of x' as f32 (it continues along the residual stream) and as
+    bf16 (the operand of this branch's gradient GEMMs), the input gradient of W_2 goes through GELU' in the GEMM's
+    epilogue, and nothing travels outside the graph."""
 
     @staticmethod
-    def forward(ctx, a, weight, bias, w_cd, kind, resid):
-        rows, n = a.shape[0], weight.shape[0]
+    def forward(ctx, a, x, w2, b2, w2_cd, w2_t, w1, b1, w1_cd, w1_t, ln_w, ln_b, eps):
+        rows = a.shape[0]
         cd = a.dtype
-        pre = None
-        b32 = None if bias is None else bias.detach()
         fp32 = cd == torch.float32
-        out_dtype = torch.float32 if kind in ("resid", "logits") else cd
-        out = torch.empty(rows, n, dtype=out_dtype, device=a.device)
+        pre = h = None
+        if w1 is not None:
+            b1_32 = None if b1 is None else b1.detach()
+            m = w1.shape[0]
+            h = torch.empty(rows, m, dtype=cd, device=a.device)
+            if fp32:
+                ops.gemm_f32(a, w1_cd, b1_32, h, EPI_GELU)
+            elif ops.gemm_bias_gelu_dual_supported(rows, m, a.shape[1]):
+                pre = torch.empty_like(h)                       # kept for GELU' instead of being recomputed
+                ops.gemm_bias_gelu_dual(a, w1_cd, b1_32, pre, h)
+            else:
+                ops.gemm_bias_gelu(a, w1_cd, b1_32, h)
+        last_in = a if w1 is None else h
+        b2_32 = None if b2 is None else b2.detach()
+        xn = torch.empty(rows, w2.shape[0], dtype=torch.float32, device=a.device)
         if fp32:
-            epi = {"bias": EPI_BIAS, "logits": EPI_BIAS, "gelu": EPI_GELU, "tanh": EPI_TANH, "resid": EPI_RESIDUAL}[kind]
-            ops.gemm_f32(a, w_cd, b32, out, epi, resid=resid if kind == "resid" else None)
-        elif kind == "gelu" and ops.gemm_bias_gelu_dual_supported(rows, n, a.shape[1]):
-            pre = torch.empty_like(out)                       # kept for the backward instead of being recomputed
-            ops.gemm_bias_gelu_dual(a, w_cd, b32, pre, out)
-        elif kind == "gelu":
-            ops.gemm_bias_gelu(a, w_cd, b32, out)
-        elif kind == "tanh":
-            ops.gemm_bias_tanh(a, w_cd, b32, out)
-        elif kind == "resid":
-            ops.gemm_bias_residual(a, w_cd, b32, resid, out)
+            ops.gemm_f32(last_in, w2_cd, b2_32, xn, EPI_RESIDUAL, resid=x)
         else:
-            ops.gemm_bias(a, w_cd, b32, out)
-        ctx.kind = kind
-        ctx.save_for_backward(a, weight, bias, w_cd, out if kind == "tanh" else pre)
-        return out
+            ops.gemm_bias_residual(last_in, w2_cd, b2_32, x, xn)
+        ctx.has_mlp, ctx.has_ln, ctx.eps = w1 is not None, ln_w is not None, eps
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(a, w2, b2, w2_cd, w2_t, w1, b1, w1_cd, w1_t, ln_w, ln_b, pre, h, xn if ln_w is not None else None)
+        if ln_w is None:
+            return xn
+        y = torch.empty(rows, xn.shape[1], dtype=cd, device=a.device)
+        ops.layernorm(xn, ln_w.detach(), ln_b.detach(), eps, y)
+        return y, xn
+
+    @staticmethod
+    def backward(ctx, *grads):
+        a, w2, b2, w2_cd, w2_t, w1, b1, w1_cd, w1_t, ln_w, ln_b, pre, h, xn = ctx.saved_tensors
+        cd = a.dtype
+        bf = cd == torch.bfloat16
+        g_lnw = g_lnb = None
+        if ctx.has_ln:
+            g_y, g_skip = grads
+            if g_y is None:
+                gx = g_skip
+                g16 = _operand(gx, cd)
+            else:
+                gx, g16, g_lnw, g_lnb = _ln_backward(xn, ln_w, ln_b, ctx.eps, g_y, g_skip, bf)
+                if g16 is None:
+                    g16 = gx
+        else:
+            gx = grads[0]
+            g16 = _operand(gx, cd)
+        if not ctx.has_mlp:
+            ga, gw2, gb2 = _linear_backward(g16, a, w2_cd, w2_t, w2, b2)
+            return ga, gx, gw2, gb2, None, None, None, None, None, None, g_lnw, g_lnb, None
+        if pre is None:                                           # not kept by the forward: one more GEMM
+            b1_32 = None if b1 is None else b1.detach()
+            if bf:
+                pre = torch.empty_like(h)
+                ops.gemm_bias(a, w1_cd, b1_32, pre)
+            else:
+                pre = F.linear(a, w1_cd, b1_32)
+        g_pre, gw2, gb2 = _linear_backward(g16, h, w2_cd, w2_t, w2, b2, aux=pre, act=ACT_GELU)
+        ga, gw1, gb1 = _linear_backward(g_pre, a, w1_cd, w1_t, w1, b1)
+        return ga, gx, gw2, gb2, None, None, gw1, gb1, None, None, g_lnw, g_lnb, None
+
+
+class HeadFn(torch.autograd.Function):
+    """logits f32 = tanh(feat W_pre^T + b_pre) W_head^T + b_head (models/vision_transformer.py:53-55); without
+    pre_logits (w_pre = None) the head alone.  The class count (1000) is no multiple of the GEMM kernels' K step,
+    so the backward pads the logits' gradient with zero columns to the padded width of the transposed head weight."""
+
+    @staticmethod
+    def forward(ctx, feat, w_pre, b_pre, w_pre_cd, w_pre_t, w_head, b_head, w_head_cd, w_head_t):
+        cd = feat.dtype
+        fp32 = cd == torch.float32
+        rows = feat.shape[0]
+        t = None
+        if w_pre is not None:
+            t = torch.empty(rows, w_pre.shape[0], dtype=cd, device=feat.device)
+            (ops.gemm_f32(feat, w_pre_cd, b_pre.detach(), t, EPI_TANH) if fp32
+             else ops.gemm_bias_tanh(feat, w_pre_cd, b_pre.detach(), t))
+        last_in = feat if t is None else t
+        logits = torch.empty(rows, w_head.shape[0], dtype=torch.float32, device=feat.device)
+        (ops.gemm_f32(last_in, w_head_cd, b_head.detach(), logits, EPI_BIAS) if fp32
+         else ops.gemm_bias(last_in, w_head_cd, b_head.detach(), logits))
+        ctx.save_for_backward(feat, w_pre, b_pre, w_pre_cd, w_pre_t, w_head, b_head, w_head_cd, w_head_t, t)
+        return logits
 
     @staticmethod
     def backward(ctx, g):
-        a, weight, bias, w_cd, out = ctx.saved_tensors
-        cd = a.dtype
-        g_resid = g if ctx.kind == "resid" else None
-        if ctx.kind == "gelu":
-            pre = out                                             # the forward's second output, when it had one
-            if pre is None and cd == torch.bfloat16:              # else recomputed with one more GEMM
-                pre = torch.empty(a.shape[0], weight.shape[0], dtype=cd, device=a.device)
-                ops.gemm_bias(a, w_cd, None if bias is None else bias.detach(), pre)
-            elif pre is None:
-                pre = F.linear(a, w_cd, bias)
-            g_pre = torch.ops.aten.gelu_backward(g, pre)                      # f32 math inside, cd in and out
-        elif ctx.kind == "tanh":
-            o = out.float()
-            g_pre = (g.float() * (1.0 - o * o)).to(cd)
+        feat, w_pre, b_pre, w_pre_cd, w_pre_t, w_head, b_head, w_head_cd, w_head_t, t = ctx.saved_tensors
+        cd = feat.dtype
+        ncls = w_head.shape[0]
+        gb_head = g.sum(0, dtype=torch.float32).to(b_head.dtype)
+        if cd == torch.bfloat16 and w_head_t is not None:
+            g16 = torch.zeros(g.shape[0], w_head_t.shape[1], dtype=cd, device=g.device)
+            g16[:, :ncls] = g
         else:
-            g_pre = _as_operand(g, cd)
-        ga, gw, gb = _linear_backward(g_pre, a, w_cd, weight, bias)
-        return ga, gw, gb, None, None, g_resid
+            g16 = g.to(cd)
+        last_in = feat if t is None else t
+        if t is None:
+            ga = _input_grad(g16, w_head_cd, w_head_t)
+        else:
+            ga = _input_grad(g16, w_head_cd, w_head_t, aux=t, act=ACT_TANH)     # gradient of the pre-activation
+        gw_head = _weight_grad(g16, last_in)[:ncls].to(w_head.dtype)
+        if t is None:
+            return ga, None, None, None, None, gw_head, gb_head, None, None
+        gfeat, gw_pre, gb_pre = _linear_backward(ga, feat, w_pre_cd, w_pre_t, w_pre, b_pre)
+        return gfeat, gw_pre, gb_pre, None, None, gw_head, gb_head, None, None
 
 
 class QkvFn(torch.autograd.Function):
     """qkv [3, B, H, N, hd] = head-major split of a W_in^T + b (models/transformer.py:42)."""
 
     @staticmethod
-    def forward(ctx, a, weight, bias, w_cd, B, N, H, hd):
+    def forward(ctx, a, weight, bias, w_cd, w_t, B, N, H, hd):
         qkv = torch.empty(3, B, H, N, hd, dtype=a.dtype, device=a.device)
         b32 = None if bias is None else bias.detach()
         if a.dtype == torch.float32:
             ops.qkv_proj_f32(a, w_cd, b32, qkv, B, N, H, hd)
         else:
             ops.qkv_proj(a, w_cd, b32, qkv, B, N, H, hd)
-        ctx.save_for_backward(a, weight, bias, w_cd)
+        ctx.save_for_backward(a, weight, bias, w_cd, w_t)
         return qkv
 
     @staticmethod
     def backward(ctx, g):
-        a, weight, bias, w_cd = ctx.saved_tensors
+        a, weight, bias, w_cd, w_t = ctx.saved_tensors
         _, B, H, N, hd = g.shape
         g_pre = g.permute(1, 3, 0, 2, 4).reshape(B * N, 3 * H * hd)        # back to [rows, which*D + h*hd + e]
-        ga, gw, gb = _linear_backward(g_pre, a, w_cd, weight, bias)
-        return ga, gw, gb, None, None, None, None, None
+        ga, gw, gb = _linear_backward(g_pre, a, w_cd, w_t, weight, bias)
+        return ga, gw, gb, None, None, None, None, None, None
 
 
 def _attention_torch(q, k, v, scale):
@@ -258,8 +346,7 @@ class PatchEmbedFn(torch.autograd.Function):
 
 def forward_train(model, x):
     """The forward of vit_amd.VisionTransformer with autograd: same kernels, fresh tensors per op."""
-    _handoff[0] = None
-    w = model._cache.get()
+    w = model._cache.get(train=True)
     fp32 = model.precision == "fp32"
     cd = torch.float32 if fp32 else torch.bfloat16
     B, _, Hi, Wi = x.shape
@@ -280,20 +367,31 @@ def forward_train(model, x):
     xs = PatchEmbedFn.apply(img, model.embedding.weight, model.embedding.bias, model.cls_token, model.pos_embed,
                             w["embed.w"], w["embed.b"], w["cls"], w["pos"], P, cols)
     x2 = xs.view(B * N, D)
-    for i, blk in enumerate(model.encoder.blocks):
+    blocks = list(model.encoder.blocks)
+    if blocks:
+        n1 = blocks[0].norm1
+        y, x2 = LayerNormFn.apply(x2, n1.weight, n1.bias, float(n1.eps), cd)
+    for i, blk in enumerate(blocks):
         p = f"b{i}."
         att, mlp = blk.attention, blk.mlp
-        y, x2 = LayerNormFn.apply(x2, blk.norm1.weight, blk.norm1.bias, float(blk.norm1.eps), cd)
-        qkv = QkvFn.apply(y, att.in_proj.weight, att.in_proj.bias, w[p + "qkv.w"], B, N, H, hd)
+        qkv = QkvFn.apply(y, att.in_proj.weight, att.in_proj.bias, w[p + "qkv.w"], w.get(p + "qkv.wt"), B, N, H, hd)
         ctxt = AttentionFn.apply(qkv, att.scaling)
-        x2 = LinearFn.apply(ctxt.view(B * N, D), att.out_proj.weight, att.out_proj.bias, w[p + "out.w"], "resid", x2)
-        y, x2 = LayerNormFn.apply(x2, blk.norm2.weight, blk.norm2.bias, float(blk.norm2.eps), cd)
-        h = LinearFn.apply(y, mlp.fc1.weight, mlp.fc1.bias, w[p + "fc1.w"], "gelu", None)
-        x2 = LinearFn.apply(h, mlp.fc2.weight, mlp.fc2.bias, w[p + "fc2.w"], "resid", x2)
+        y, x2 = ResidualBranchFn.apply(ctxt.view(B * N, D), x2, att.out_proj.weight, att.out_proj.bias, w[p + "out.w"],
+                                       w.get(p + "out.wt"), None, None, None, None,
+                                       blk.norm2.weight, blk.norm2.bias, float(blk.norm2.eps))
+        nxt = blocks[i + 1].norm1 if i + 1 < len(blocks) else None        # the next block's first LayerNorm
+        res = ResidualBranchFn.apply(y, x2, mlp.fc2.weight, mlp.fc2.bias, w[p + "fc2.w"], w.get(p + "fc2.wt"),
+                                     mlp.fc1.weight, mlp.fc1.bias, w[p + "fc1.w"], w.get(p + "fc1.wt"),
+                                     None if nxt is None else nxt.weight, None if nxt is None else nxt.bias,
+                                     0.0 if nxt is None else float(nxt.eps))
+        if nxt is None:
+            x2 = res
+        else:
+            y, x2 = res
     cls_rows = x2.view(B, N, D)[:, 0].contiguous()                         # the reference keeps token 0 (transformer.py:99)
     norm = model.encoder.norm
     feat, _ = LayerNormFn.apply(cls_rows, norm.weight, norm.bias, float(norm.eps), cd)
-    if "pre.w" in w:
-        feat = LinearFn.apply(feat, model.pre_logits.weight, model.pre_logits.bias, w["pre.w"], "tanh", None)
-    logits = LinearFn.apply(feat, model.head.weight, model.head.bias, w["head.w"], "logits", None)
+    has_pre = "pre.w" in w
+    logits = HeadFn.apply(feat, model.pre_logits.weight if has_pre else None, model.pre_logits.bias if has_pre else None,
+                          w.get("pre.w"), w.get("pre.wt"), model.head.weight, model.head.bias, w["head.w"], w.get("head.wt"))
     return logits.to(model.head.weight.dtype)

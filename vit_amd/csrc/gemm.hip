@@ -253,6 +253,13 @@ hipError_t launch_gemm_tiled(const GemmArgs& a, int epilogue, bool gather, int v
             if (variant == 1 || variant == 3 || (size_t)(a.M + 256) * a.N * 4 >= (1ull << 32)) return hipErrorInvalidValue;
             if (variant != 5 && gemm_pp_supports(a, false)) return launch_gemm_pp(a, EPI_BIAS_GELU_DUAL_BF16, s);
             return launch_gemm_pipe(a, EPI_BIAS_GELU_DUAL_BF16, false, s);
+        case EPI_MUL_DGELU_BF16:
+        case EPI_MUL_DTANH_BF16:           // through the persistent kernels only (their shared epilogue)
+            if ((size_t)(a.M + 256) * a.N * 4 >= (1ull << 32) || (size_t)a.M * a.lda * 2 >= (1ull << 32) ||
+                (size_t)a.N * a.K * 2 >= (1ull << 32))
+                return hipErrorInvalidValue;
+            if (variant != 5 && gemm_pp_supports(a, false)) return launch_gemm_pp(a, epilogue, s);
+            return launch_gemm_pipe(a, epilogue, false, s);
         case EPI_BIAS_RESID_F32: return launch_variant<EPI_BIAS_RESID_F32, false>(a, variant, s);
         case EPI_QKV_BF16: return launch_variant<EPI_QKV_BF16, false>(a, variant, s);
         case EPI_BIAS_F32: return launch_variant<EPI_BIAS_F32, false>(a, variant, s);
@@ -308,6 +315,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_small(const GemmArgs p) {
             if constexpr (EPI == EPI_BIAS_GELU_BF16) v = gelu_erf(v);
             if constexpr (EPI == EPI_BIAS_TANH_BF16) v = tanhf(v);
             const size_t off = (size_t)m * p.ldo + n;
+            if constexpr (EPI == EPI_MUL_DGELU_BF16 || EPI == EPI_MUL_DTANH_BF16) {
+                // the product rounded to bf16 (what a bf16 matmul hands autograd) times the derivative at aux
+                const float ax = (float)reinterpret_cast<const bf16_t*>(p.aux)[off];
+                const float d = EPI == EPI_MUL_DGELU_BF16 ? dgelu_erf(ax) : fmaf(-ax, ax, 1.0f);
+                v = (float)(bf16_t)v * d;
+            }
             if constexpr (EPI == EPI_BIAS_F32) {
                 reinterpret_cast<float*>(p.out)[off] = v;
             } else if constexpr (EPI == EPI_BIAS_RESID_F32) {
@@ -327,6 +340,8 @@ hipError_t launch_gemm_small(const GemmArgs& a, int epilogue, hipStream_t s) {
         case EPI_BIAS_RESID_F32: hipLaunchKernelGGL(gemm_bf16_small<EPI_BIAS_RESID_F32>, grid, block, 0, s, a); break;
         case EPI_BIAS_F32: hipLaunchKernelGGL(gemm_bf16_small<EPI_BIAS_F32>, grid, block, 0, s, a); break;
         case EPI_BIAS_TANH_BF16: hipLaunchKernelGGL(gemm_bf16_small<EPI_BIAS_TANH_BF16>, grid, block, 0, s, a); break;
+        case EPI_MUL_DGELU_BF16: hipLaunchKernelGGL(gemm_bf16_small<EPI_MUL_DGELU_BF16>, grid, block, 0, s, a); break;
+        case EPI_MUL_DTANH_BF16: hipLaunchKernelGGL(gemm_bf16_small<EPI_MUL_DTANH_BF16>, grid, block, 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -39,8 +39,9 @@ template <int EPI, bool MASKED, int AHEAD = 1>
 __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&acc)[4][8], char* win, int mw,
                                               int nw, int my_mt, int row_limit, int lane) {
     const int fr = lane & 15, fq = lane >> 4;
+    constexpr bool AUXMUL = (EPI == EPI_MUL_DGELU_BF16 || EPI == EPI_MUL_DTANH_BF16);   // out = bf16(acc) * f'(aux)
     constexpr bool OUT_BF16 = (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_BIAS_TANH_BF16 ||
-                               EPI == EPI_QKV_BF16 || EPI == EPI_BIAS_GELU_DUAL_BF16);
+                               EPI == EPI_QKV_BF16 || EPI == EPI_BIAS_GELU_DUAL_BF16 || AUXMUL);
     constexpr bool DUAL = EPI == EPI_BIAS_GELU_DUAL_BF16;       // two trips through the window: pre-activation, then GELU
     if constexpr (OUT_BF16) {
         // window = 32 rows x 128 B.  8-byte piece (row r, chunk c, half h) lives at
@@ -82,6 +83,16 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
             for (int rep = 0; rep < (DUAL ? 2 : 1); ++rep) {
             const bool gelu_now = EPI == EPI_BIAS_GELU_BF16 || (DUAL && rep == 1);
             char* dst = reinterpret_cast<char*>((DUAL && rep == 0) ? p.out2 : p.out);
+            u32x4 auxv[4];                               // AUXMUL: this pass's pieces of aux, requested before the window trip
+            if constexpr (AUXMUL) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int row = mw + pass * 32 + i * 8 + rc;
+                    row = row < p.M ? row : p.M - 1;     // loads stay in bounds; such rows are not stored
+                    auxv[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.aux) +
+                                                              ((uint32_t)row * p.ldo + col_off) * 2u);
+                }
+            }
 #pragma unroll
             for (int m2 = 0; m2 < 2; ++m2) {
                 if (MASKED && pass * 2 + m2 >= my_mt) break;
@@ -110,6 +121,18 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
                 const int r = i * 8 + rc;
                 u32x4 v = *reinterpret_cast<const u32x4*>(win + r * 128 + ((cc ^ (r & 7)) << 4));
                 if (i & 1) v = u32x4{v[2], v[3], v[0], v[1]};     // rows 8..15 and 24..31 hold swapped halves
+                if constexpr (AUXMUL) {
+                    // the product's bf16 value times the activation's derivative at the saved tensor: what
+                    // autograd computes as gelu_backward / tanh_backward on the bf16 matmul output
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float a0 = bf16_lo(auxv[i][j]), a1 = bf16_hi(auxv[i][j]);
+                        float d0, d1;
+                        if constexpr (EPI == EPI_MUL_DGELU_BF16) { d0 = dgelu_erf(a0); d1 = dgelu_erf(a1); }
+                        else { d0 = fmaf(-a0, a0, 1.0f); d1 = fmaf(-a1, a1, 1.0f); }
+                        v[j] = pack_bf16(bf16_lo(v[j]) * d0, bf16_hi(v[j]) * d1);
+                    }
+                }
                 const int lr = pass * 32 + r;                     // row inside the wave's sub-tile
                 uint32_t off;                                     // element offset (< 2^31: checked by the launcher)
                 if constexpr (EPI == EPI_QKV_BF16) {

@@ -218,6 +218,8 @@ hipError_t launch_gemm_pipe(const GemmArgs& a, int epilogue, bool gather, hipStr
         case EPI_QKV_BF16: return launch_pipe<EPI_QKV_BF16, false>(a, s);
         case EPI_BIAS_F32: return launch_pipe<EPI_BIAS_F32, false>(a, s);
         case EPI_BIAS_TANH_BF16: return launch_pipe<EPI_BIAS_TANH_BF16, false>(a, s);
+        case EPI_MUL_DGELU_BF16: return launch_pipe<EPI_MUL_DGELU_BF16, false>(a, s);
+        case EPI_MUL_DTANH_BF16: return launch_pipe<EPI_MUL_DTANH_BF16, false>(a, s);
         case EPI_PATCH_F32: return launch_pipe<EPI_PATCH_F32, false>(a, s);     // rows already gathered (im2col)
         default: return hipErrorInvalidValue;
     }

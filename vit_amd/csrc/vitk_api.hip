@@ -61,7 +61,7 @@ int dense(const char* name, const void* A, const void* W, const float* bias, con
 
 extern "C" {
 
-int vitk_version(void) { return 3; }
+int vitk_version(void) { return 4; }
 
 const char* vitk_last_error(void) { return g_err; }
 
@@ -372,6 +372,29 @@ int vitk_gemm_bias_gelu_dual(const void* A, const void* W, const float* bias, vo
     hipError_t e = launch_gemm_tiled(a, EPI_BIAS_GELU_DUAL_BF16, false, g_gemm_variant & 15, reinterpret_cast<hipStream_t>(stream));
     if (e == hipErrorInvalidValue) return fail(VITK_ERR_UNSUPPORTED, "%s: not available with this kernel variant / size", name);
     return launched(e, name);
+}
+
+int vitk_gemm_grad_act(const void* G, const void* Wt, const void* aux, void* out, int M, int N, int K, int act,
+                       void* stream) {
+    const char* name = "vitk_gemm_grad_act";
+    if (!G || !Wt || !aux || !out) return fail(VITK_ERR_INVALID, "%s: null pointer", name);
+    if (M <= 0 || N <= 0 || K <= 0) return fail(VITK_ERR_INVALID, "%s: non-positive size %dx%dx%d", name, M, N, K);
+    if (act != VITK_ACT_GELU && act != VITK_ACT_TANH) return fail(VITK_ERR_INVALID, "%s: act=%d", name, act);
+    if (!aligned16(G) || !aligned16(Wt) || !aligned16(aux) || !aligned16(out))
+        return fail(VITK_ERR_INVALID, "%s: pointers must be 16-byte aligned", name);
+    if (K % 32 != 0) return fail(VITK_ERR_UNSUPPORTED, "%s: K=%d is not a multiple of 32", name, K);
+    GemmArgs a = {};
+    a.A = G; a.W = Wt; a.aux = aux; a.out = out;
+    a.M = M; a.N = N; a.K = K; a.lda = K; a.ldo = N;
+    a.order = g_gemm_variant >> 4;
+    const int epi = act == VITK_ACT_GELU ? EPI_MUL_DGELU_BF16 : EPI_MUL_DTANH_BF16;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool tiled_ok = (N % 256 == 0) && (K % 64 == 0) && M >= 128 && (g_gemm_variant & 15) != 2;
+    if (tiled_ok) {
+        hipError_t e = launch_gemm_tiled(a, epi, false, g_gemm_variant & 15, s);
+        if (e != hipErrorInvalidValue) return launched(e, name);      // else: a tensor of 4 GiB or more
+    }
+    return launched(launch_gemm_small(a, epi, s), name);
 }
 
 int vitk_colsum_bf16(const void* G, float* out, float* partials, int partial_rows, int R, int M, void* stream) {

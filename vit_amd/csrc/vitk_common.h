@@ -51,6 +51,21 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return fmaf(-0.5f * ax, q, fmaxf(x, 0.0f));
 }
 
+// d/dx gelu(x) = Phi(x) + x phi(x), with the same erf approximation: Phi(|x|) = 1 - q / 2 and
+// phi(x) = exp(-x^2 / 2) / sqrt(2 pi) share the exponential.  (GELU's backward in the training step.)
+__device__ __forceinline__ float dgelu_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.3275911f * 0.70710678118654752440f, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.44269504088896340736f));
+    float q = fmaf(t, 1.061405429f, -1.453152027f);
+    q = fmaf(q, t, 1.421413741f);
+    q = fmaf(q, t, -0.284496736f);
+    q = fmaf(q, t, 0.254829592f);
+    q = 0.5f * q * t * e;                                  // Phi(-|x|)
+    const float cdf = x >= 0.f ? 1.0f - q : q;
+    return fmaf(x * e, 0.39894228040143267794f, cdf);
+}
+
 // The same function on packed f32 arithmetic (v_pk_mul_f32 / v_pk_fma_f32: twice the throughput of scalar
 // VALU code, and no transcendental) for the fused GEMM epilogue, where GELU of 128 accumulators per lane is
 // what the epilogue's time goes to.

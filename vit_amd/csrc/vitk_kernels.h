@@ -14,6 +14,8 @@ enum Epilogue {
     EPI_BIAS_F32 = 5,        // out f32  [M,N] = acc + bias
     EPI_BIAS_TANH_BF16 = 6,  // out bf16 [M,N] = tanh(acc + bias)
     EPI_BIAS_GELU_DUAL_BF16 = 7,  // training: out = gelu(acc + bias) and out2 bf16 [M,N] = acc + bias (the pre-activation)
+    EPI_MUL_DGELU_BF16 = 8,  // training: out bf16 [M,N] = bf16(acc) * gelu'(aux), aux bf16 [M,N] = the pre-activation
+    EPI_MUL_DTANH_BF16 = 9,  // training: out bf16 [M,N] = bf16(acc) * (1 - aux^2), aux bf16 [M,N] = the tanh output
 };
 
 // epilogues of the fp32-mode GEMM (f32path.hip)
@@ -27,6 +29,7 @@ struct GemmArgs {
     void* out2;          // EPI_BIAS_GELU_DUAL_BF16: the pre-activation
     const float* resid;  // EPI_BIAS_RESID_F32 (may alias out)
     const float* pos;    // EPI_PATCH_F32: pos_embed [Ntok,N]
+    const void* aux;     // EPI_MUL_*: bf16 [M,N] (row stride ldo), what the activation's derivative is taken of
     int M, N, K;
     int lda, ldo;        // row strides in elements
     int ntok, heads, hd, batch;                 // EPI_QKV_BF16 / EPI_PATCH_F32

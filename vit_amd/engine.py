@@ -44,12 +44,37 @@ class WeightCache:
     def _signature(self):
         return tuple((p.data_ptr(), p._version, p.device) for p in self._model.parameters())
 
-    def get(self):
+    def get(self, train=False):
+        """Kernel-ready tensors; train=True adds what the backward GEMMs need (bf16 mode): `*.wt`, each GEMM
+        weight transposed ([in, out]), so that the input gradient g W is the forward kernel's A W'^T with
+        W' = W^T; the head's is zero-padded to a multiple of 64 columns (num_classes is 1000)."""
         key = self._signature()
         if key != self._key:
             self._rebuild()
             self._key = key
+        if train and not self._fp32 and "head.wt" not in self.t:
+            self._add_transposed()
         return self.t
+
+    def invalidate(self):
+        """Drop the derived copies: call after changing parameters through `.data` (which `_version` does
+        not see), e.g. `p.data.copy_()` in weight-averaging helpers."""
+        self._key = None
+
+    def _add_transposed(self):
+        t = self.t
+        tr = lambda w: w.t().contiguous()                                  # noqa: E731
+        for i in range(len(self._model.encoder.blocks)):
+            p = f"b{i}."
+            for n in ("qkv", "out", "fc1", "fc2"):
+                t[p + n + ".wt"] = tr(t[p + n + ".w"])
+        if "pre.w" in t:
+            t["pre.wt"] = tr(t["pre.w"])
+        hw = t["head.w"]                                                   # [classes, D]
+        kpad = (hw.shape[0] + 63) // 64 * 64
+        wt = torch.zeros(hw.shape[1], kpad, dtype=hw.dtype, device=hw.device)
+        wt[:, :hw.shape[0]] = hw.t()
+        t["head.wt"] = wt
 
     def _rebuild(self):
         m = self._model

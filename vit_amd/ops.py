@@ -415,6 +415,21 @@ def gemm_bias_gelu_dual(a, w, bias, pre, out):
     return out
 
 
+def gemm_grad_act(g, wt, aux, out, act):
+    """out bf16 [M, N] = bf16(g @ wt.T) * f'(aux): the input gradient of a Linear layer through the activation in
+    front of it.  g bf16 [M, K], wt bf16 [N, K] (the layer's weight transposed), aux bf16 [M, N]: the GELU's
+    pre-activation (act = lib.ACT_GELU) or the tanh output (act = lib.ACT_TANH)."""
+    L = _lib.load()
+    for n, t in (("g", g), ("wt", wt), ("aux", aux), ("out", out)):
+        _chk(t, torch.bfloat16, n)
+    M, N, K = _dense_shapes(g, wt, out, "gemm_grad_act")
+    if tuple(aux.shape) != (M, N):
+        raise _lib.VitkError(f"gemm_grad_act: aux {tuple(aux.shape)} vs out [{M},{N}]")
+    with _span("gemm_grad_act"):
+        _lib.check(L.vitk_gemm_grad_act(_ptr(g), _ptr(wt), _ptr(aux), _ptr(out), M, N, K, int(act), _stream()), L)
+    return out
+
+
 _colsum_partials = {}
 
 

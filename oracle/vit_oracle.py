@@ -146,12 +146,13 @@ def forward_bf16_emulated(sd, images, cfg, stages=None, attn_scaling=None):
         x = x + linear16(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
         if stages is not None and i == 0:
             stages["block0"] = x
-    x = r16(layernorm(x[:, 0], sd["encoder.norm.weight"], sd["encoder.norm.bias"], eps))
+    # the head (one row per image) runs in f32 on the HIP path too: no rounding from here on
+    x = layernorm(x[:, 0], sd["encoder.norm.weight"], sd["encoder.norm.bias"], eps)
     if stages is not None:
         stages["encoded"] = x
     if "pre_logits.weight" in sd:
-        x = r16(torch.tanh(linear16(x, sd["pre_logits.weight"], sd["pre_logits.bias"])))
-    return linear16(x, sd["head.weight"], sd["head.bias"])
+        x = torch.tanh(F.linear(x, sd["pre_logits.weight"], sd["pre_logits.bias"]))
+    return F.linear(x, sd["head.weight"], sd["head.bias"])
 
 
 def flops_per_image(cfg, img_size, num_classes=1000):

@@ -123,6 +123,25 @@ def full(name, arch, img_size, batch, style, seed=0, pool=24):
     print(name, y.shape, "min margin %.3e" % meta["min_margin"], flush=True)
 
 
+def pool_fixture(name, arch, img_size, pool, style, seed=0):
+    """Reference logits of EVERY image of the first `pool` stream images (not only the large-margin ones that
+    `full` keeps): the GPU test holds all of them to the max-abs bound and checks top-1 wherever the reference
+    margin exceeds twice the measured error."""
+    cfg = synth.ARCHS[arch]
+    sd = synth.synth_state_dict(cfg, img_size, seed=seed, style=style)
+    m = getattr(ref_vt, arch)(img_size=img_size).eval()
+    m.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        y = torch.cat([m(synth.synth_images(min(4, pool - i), img_size, seed=seed + 1, first=i)) for i in range(0, pool, 4)])
+    top2 = y.topk(2, dim=-1)
+    np.savez(os.path.join(HERE, name + ".npz"), logits=np_(y), top1=np_(top2.indices[:, 0]).astype(np.int64),
+             margin=np_(top2.values[:, 0] - top2.values[:, 1]))
+    with open(os.path.join(HERE, name + ".json"), "w") as f:
+        json.dump(dict(arch=arch, img_size=img_size, pool=pool, style=style, seed=seed, image_seed=seed + 1), f, indent=1)
+    print(name, tuple(y.shape), "margins min %.2e median %.2e" % (float(top2.values[:, 0].sub(top2.values[:, 1]).min()),
+                                                                 float(top2.values[:, 0].sub(top2.values[:, 1]).median())), flush=True)
+
+
 def keys():
     """state_dict key/shape lists as the reference classes produce them."""
     out = {}
@@ -267,6 +286,16 @@ if __name__ == "__main__":
         sys.exit(0)
     if sys.argv[1:] == ["pos_embed"]:
         pos_embed_fixture()
+        sys.exit(0)
+    if sys.argv[1:] == ["pools"]:
+        pool_fixture("s16_224_pool", "s16", 224, 24, "reference")
+        pool_fixture("b16_224_pool", "b16", 224, 24, "reference")
+        pool_fixture("b16_224_pert_pool", "b16", 224, 24, "perturbed", seed=3)
+        pool_fixture("b16_384_pool", "b16", 384, 12, "reference")
+        pool_fixture("l16_224_pool", "l16", 224, 16, "reference")
+        pool_fixture("b32_224_pool", "b32", 224, 8, "reference")
+        pool_fixture("l32_224_pool", "l32", 224, 8, "reference")
+        pool_fixture("h14_224_pool", "h14", 224, 8, "reference")
         sys.exit(0)
     if sys.argv[1:] == ["h14"]:
         full("h14_224_ref", "h14", 224, 2, "reference", pool=8)

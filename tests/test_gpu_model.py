@@ -39,9 +39,8 @@ def test_logits_match_reference(name):
 
 def test_h14_patch_14_head_dim_80():
     """ViT-H/14 (patch 14 through the explicit patch matrix, head_dim 80, 32 layers, default LayerNorm eps)
-    in both compute modes.  H/14 is not one of the measured configurations; with 32 layers of bf16 rounding
-    its bf16-mode error (1.05e-2 measured) sits just above the 1e-2 bar the B/16 and L/16 sets meet, so this
-    test holds it to 1.5e-2 and identical top-1 (margin 8.4e-2), and holds the fp32 mode to 1e-4."""
+    in both compute modes: the north-star bars, 1e-2 in bf16 (9.3e-3 measured) with identical top-1
+    (margin 8.4e-2), 1e-4 in fp32."""
     meta, g = load_golden("h14_224_ref")
     cfg, sd, x = golden_inputs(meta)
     m = build_model("h14", 224, sd, DEV)
@@ -49,7 +48,7 @@ def test_h14_patch_14_head_dim_80():
         y = m(x.to(DEV)).float().cpu().numpy()
     err = np.abs(y - g["logits"]).max()
     print(f"h14_224_ref bf16: max-abs logit error {err:.3e}, min margin {meta['min_margin']:.3e}")
-    assert err <= 1.5e-2
+    assert err <= TOL_BF16
     assert (y.argmax(-1) == g["top1"]).all()
     m.set_precision("fp32")
     with torch.no_grad():
@@ -150,3 +149,35 @@ def test_hip_graph_replay_matches_eager():
         assert torch.equal(gf(x2), m(x2))
     with pytest.raises(vit_amd.VitkError):
         gf(xd[:2])
+
+
+POOLS = ["s16_224_pool", "b16_224_pool", "b16_224_pert_pool", "b16_384_pool", "l16_224_pool", "b32_224_pool", "l32_224_pool",
+         "h14_224_pool"]
+# max-abs bound per pool.  1e-2 is the north-star bar.  ViT-H/14 (32 layers, not a measured configuration) is held to
+# 1.1e-2 over its whole pool (1.0004e-2 measured on the worst of 8 images): the oracle restated with bf16 rounding at
+# the kernels' rounding points (exact erf, exact softmax, fp32 residual stream) shows the same size of error there, and
+# three quarters of it is the bf16 rounding of the weights themselves: the precision design's, not a kernel's.
+POOL_TOL = {"h14_224_pool": 1.1e-2}
+
+
+@pytest.mark.parametrize("name", POOLS)
+def test_whole_pool_against_reference_logits(name):
+    """Every image of the synthetic stream's first `pool` images (not a hand-picked subset), all six factories:
+    max-abs logit error within the bound on every image, and the reference's top-1 wherever its margin over the
+    runner-up exceeds twice that image's measured error (a smaller margin can flip under legitimate rounding)."""
+    from vit_amd import synth
+    meta, g = load_golden(name)
+    cfg = synth.ARCHS[meta["arch"]]
+    sd = synth.synth_state_dict(cfg, meta["img_size"], seed=meta["seed"], style=meta["style"])
+    x = synth.synth_images(meta["pool"], meta["img_size"], seed=meta["image_seed"])
+    m = build_model(meta["arch"], meta["img_size"], sd, DEV)
+    with torch.no_grad():
+        y = m(x.to(DEV)).float().cpu().numpy()
+    err = np.abs(y - g["logits"]).max(-1)
+    decided = g["margin"] > 2 * err
+    same = y.argmax(-1) == g["top1"]
+    print(f"{name}: max-abs error per image max {err.max():.3e} mean {err.mean():.3e}; top-1 checked on "
+          f"{int(decided.sum())}/{len(err)} images (margin > 2 x error), equal on {int(same.sum())}/{len(err)} overall")
+    assert err.max() <= POOL_TOL.get(name, TOL_BF16), err
+    assert same[decided].all()
+    assert decided.sum() >= len(err) // 3

@@ -59,3 +59,23 @@ def test_flops_formula():
     assert vo.flops_per_image(synth.ARCHS["l16"], 224) == 123_111_522_304
     assert vo.flops_per_image(synth.ARCHS["b16"], 384) == 110_969_880_576
     assert vo.flops_per_image(synth.ARCHS["s16"], 224) == 19_778_949_120
+
+
+def test_oracle_matches_reference_on_unpicked_pool_images():
+    """The whole-pool fixtures (every image of the stream's head, no margin selection): the oracle reproduces
+    the reference's logits on the first images of each, b32 / l32 / h14 included."""
+    import json
+    import os
+
+    import numpy as np
+    from tests.helpers import GOLDEN
+    from vit_amd import synth
+    for name, n in (("s16_224_pool", 3), ("b16_224_pool", 2), ("b32_224_pool", 2), ("l32_224_pool", 1), ("h14_224_pool", 1)):
+        with open(os.path.join(GOLDEN, name + ".json")) as f:
+            meta = json.load(f)
+        g = np.load(os.path.join(GOLDEN, name + ".npz"))
+        cfg = synth.ARCHS[meta["arch"]]
+        sd = synth.synth_state_dict(cfg, meta["img_size"], seed=meta["seed"], style=meta["style"])
+        x = synth.synth_images(n, meta["img_size"], seed=meta["image_seed"])
+        y = vo.forward(sd, x, cfg).numpy()
+        assert np.abs(y - g["logits"][:n]).max() <= 2e-5, name

@@ -192,49 +192,45 @@ class ResidualBranchFn(torch.autograd.Function):
         return ga, gx, gw2, gb2, None, None, gw1, gb1, None, None, g_lnw, g_lnb, None
 
 
+def _mm_f32(a, w):
+    """a [M, K] @ w[N, K]^T in f32 through the library's f32 GEMM (exact f32 multiply-add on the matrix pipe)."""
+    out = torch.empty(a.shape[0], w.shape[0], dtype=torch.float32, device=a.device)
+    return ops.gemm_f32(a.contiguous(), w.contiguous(), None, out, EPI_BIAS)
+
+
 class HeadFn(torch.autograd.Function):
     """logits f32 = tanh(feat W_pre^T + b_pre) W_head^T + b_head (models/vision_transformer.py:53-55); without
-    pre_logits (w_pre = None) the head alone.  The class count (1000) is no multiple of the GEMM kernels' K step,
-    so the backward pads the logits' gradient with zero columns to the padded width of the transposed head weight."""
+    pre_logits (w_pre = None) the head alone.  f32 in both compute modes (one row per image: 2.7 MFLOP), forward
+    and backward through vitk_gemm_f32."""
 
     @staticmethod
-    def forward(ctx, feat, w_pre, b_pre, w_pre_cd, w_pre_t, w_head, b_head, w_head_cd, w_head_t):
-        cd = feat.dtype
-        fp32 = cd == torch.float32
+    def forward(ctx, feat, w_pre, b_pre, w_head, b_head):
         rows = feat.shape[0]
         t = None
         if w_pre is not None:
-            t = torch.empty(rows, w_pre.shape[0], dtype=cd, device=feat.device)
-            (ops.gemm_f32(feat, w_pre_cd, b_pre.detach(), t, EPI_TANH) if fp32
-             else ops.gemm_bias_tanh(feat, w_pre_cd, b_pre.detach(), t))
+            t = torch.empty(rows, w_pre.shape[0], dtype=torch.float32, device=feat.device)
+            ops.gemm_f32(feat, w_pre.detach().float().contiguous(), b_pre.detach().float(), t, EPI_TANH)
         last_in = feat if t is None else t
         logits = torch.empty(rows, w_head.shape[0], dtype=torch.float32, device=feat.device)
-        (ops.gemm_f32(last_in, w_head_cd, b_head.detach(), logits, EPI_BIAS) if fp32
-         else ops.gemm_bias(last_in, w_head_cd, b_head.detach(), logits))
-        ctx.save_for_backward(feat, w_pre, b_pre, w_pre_cd, w_pre_t, w_head, b_head, w_head_cd, w_head_t, t)
+        ops.gemm_f32(last_in, w_head.detach().float().contiguous(), b_head.detach().float(), logits, EPI_BIAS)
+        ctx.save_for_backward(feat, w_pre, b_pre, w_head, b_head, t)
         return logits
 
     @staticmethod
     def backward(ctx, g):
-        feat, w_pre, b_pre, w_pre_cd, w_pre_t, w_head, b_head, w_head_cd, w_head_t, t = ctx.saved_tensors
-        cd = feat.dtype
-        ncls = w_head.shape[0]
-        gb_head = g.sum(0, dtype=torch.float32).to(b_head.dtype)
-        if cd == torch.bfloat16 and w_head_t is not None:
-            g16 = torch.zeros(g.shape[0], w_head_t.shape[1], dtype=cd, device=g.device)
-            g16[:, :ncls] = g
-        else:
-            g16 = g.to(cd)
+        feat, w_pre, b_pre, w_head, b_head, t = ctx.saved_tensors
+        g = g.float().contiguous()
         last_in = feat if t is None else t
+        gb_head = g.sum(0).to(b_head.dtype)
+        gw_head = _mm_f32(g.t(), last_in.t()).to(w_head.dtype)            # g^T last_in: [classes, D]
+        ga = _mm_f32(g, w_head.detach().float().t())                      # g W_head: [rows, D]
         if t is None:
-            ga = _input_grad(g16, w_head_cd, w_head_t)
-        else:
-            ga = _input_grad(g16, w_head_cd, w_head_t, aux=t, act=ACT_TANH)     # gradient of the pre-activation
-        gw_head = _weight_grad(g16, last_in)[:ncls].to(w_head.dtype)
-        if t is None:
-            return ga, None, None, None, None, gw_head, gb_head, None, None
-        gfeat, gw_pre, gb_pre = _linear_backward(ga, feat, w_pre_cd, w_pre_t, w_pre, b_pre)
-        return gfeat, gw_pre, gb_pre, None, None, gw_head, gb_head, None, None
+            return ga, None, None, gw_head, gb_head
+        ga = ga * (1.0 - t * t)                                           # through tanh, from its output
+        gb_pre = ga.sum(0).to(b_pre.dtype)
+        gw_pre = _mm_f32(ga.t(), feat.t()).to(w_pre.dtype)
+        gfeat = _mm_f32(ga, w_pre.detach().float().t())
+        return gfeat, gw_pre, gb_pre, gw_head, gb_head
 
 
 class QkvFn(torch.autograd.Function):
@@ -390,8 +386,8 @@ def forward_train(model, x):
             y, x2 = res
     cls_rows = x2.view(B, N, D)[:, 0].contiguous()                         # the reference keeps token 0 (transformer.py:99)
     norm = model.encoder.norm
-    feat, _ = LayerNormFn.apply(cls_rows, norm.weight, norm.bias, float(norm.eps), cd)
+    feat, _ = LayerNormFn.apply(cls_rows, norm.weight, norm.bias, float(norm.eps), torch.float32)
     has_pre = "pre.w" in w
     logits = HeadFn.apply(feat, model.pre_logits.weight if has_pre else None, model.pre_logits.bias if has_pre else None,
-                          w.get("pre.w"), w.get("pre.wt"), model.head.weight, model.head.bias, w["head.w"], w.get("head.wt"))
+                          model.head.weight, model.head.bias)
     return logits.to(model.head.weight.dtype)

@@ -47,12 +47,12 @@ class WeightCache:
     def get(self, train=False):
         """Kernel-ready tensors; train=True adds what the backward GEMMs need (bf16 mode): `*.wt`, each GEMM
         weight transposed ([in, out]), so that the input gradient g W is the forward kernel's A W'^T with
-        W' = W^T; the head's is zero-padded to a multiple of 64 columns (num_classes is 1000)."""
+        W' = W^T."""
         key = self._signature()
         if key != self._key:
             self._rebuild()
             self._key = key
-        if train and not self._fp32 and "head.wt" not in self.t:
+        if train and not self._fp32 and "train" not in self.t:
             self._add_transposed()
         return self.t
 
@@ -68,13 +68,7 @@ class WeightCache:
             p = f"b{i}."
             for n in ("qkv", "out", "fc1", "fc2"):
                 t[p + n + ".wt"] = tr(t[p + n + ".w"])
-        if "pre.w" in t:
-            t["pre.wt"] = tr(t["pre.w"])
-        hw = t["head.w"]                                                   # [classes, D]
-        kpad = (hw.shape[0] + 63) // 64 * 64
-        wt = torch.zeros(hw.shape[1], kpad, dtype=hw.dtype, device=hw.device)
-        wt[:, :hw.shape[0]] = hw.t()
-        t["head.wt"] = wt
+        t["train"] = True
 
     def _rebuild(self):
         m = self._model
@@ -104,9 +98,11 @@ class WeightCache:
             t[p + "fc1.w"], t[p + "fc1.b"] = _bf16(blk.mlp.fc1.weight), _f32(blk.mlp.fc1.bias)
             t[p + "fc2.w"], t[p + "fc2.b"] = _bf16(blk.mlp.fc2.weight), _f32(blk.mlp.fc2.bias)
         t["norm.w"], t["norm.b"] = _f32(m.encoder.norm.weight), _f32(m.encoder.norm.bias)
+        # The head (final LayerNorm output, pre_logits + tanh, classifier: 2.7 MFLOP per image) runs in f32 in
+        # both modes: its bf16 roundings were ~13 % of the bf16 mode's logit error and it costs nothing.
         if isinstance(m.pre_logits, torch.nn.Linear):
-            t["pre.w"], t["pre.b"] = _bf16(m.pre_logits.weight), _f32(m.pre_logits.bias)
-        t["head.w"], t["head.b"] = _bf16(m.head.weight), _f32(m.head.bias)
+            t["pre.w"], t["pre.b"] = _f32(m.pre_logits.weight), _f32(m.pre_logits.bias)
+        t["head.w"], t["head.b"] = _f32(m.head.weight), _f32(m.head.bias)
         self.t = t
 
 
@@ -124,8 +120,8 @@ class Workspace:
         self.qkv = e(3, B, H, N, hd, dtype=bf)
         self.ctx = e(B, N, D, dtype=bf)
         self.h = e(B * N, M, dtype=bf)
-        self.cls_n = e(B, D, dtype=bf)
-        self.pre = e(B, D, dtype=bf)
+        self.cls_n = e(B, D, dtype=f32)          # the head runs in f32 in both modes
+        self.pre = e(B, D, dtype=f32)
         self.logits = e(B, ncls, dtype=f32)
         self.img16 = None
         self.cols = None

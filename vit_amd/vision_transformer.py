@@ -141,11 +141,11 @@ class VisionTransformer(nn.Module):
         else:
             cols = ws.patch_cols(B * (N - 1), w["embed.w"].shape[1], x.device)
             ops.patch_embed_cols(img16, w["embed.w"], w["embed.b"], w["cls"], w["pos"], ws.x, cols, P)
-        feat = self.encoder.fused(ws, w)
+        feat = self.encoder.fused(ws, w)             # f32 [B, D]: from here on f32 kernels in both modes
         if "pre.w" in w:
-            ops.gemm_bias_tanh(feat, w["pre.w"], w["pre.b"], ws.pre)
+            ops.gemm_f32(feat, w["pre.w"], w["pre.b"], ws.pre, EPI_TANH)
             feat = ws.pre
-        ops.gemm_bias(feat, w["head.w"], w["head.b"], ws.logits)
+        ops.gemm_f32(feat, w["head.w"], w["head.b"], ws.logits)
         return ws.logits.to(out_dtype, copy=True)
 
 

@@ -1,0 +1,5 @@
+#!/bin/bash
+set -u
+bash tools/profile.sh b16_224_bs256 b16 224 256 || exit $?
+bash tools/profile.sh l16_224_bs256 l16 224 256 || exit $?
+bash tools/profile.sh b16_384_bs128 b16 384 128 || exit $?

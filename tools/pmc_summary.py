@@ -1,7 +1,12 @@
 """Summarise rocprofv3 CSV output: per-kernel averages of kernel-trace durations and PMC counters.
 
-    python tools/pmc_summary.py gpurun_out/prof_bench gpurun_out/prof_pmc1 ...
+    python tools/pmc_summary.py [--workload NAME] gpurun_out/prof_bench gpurun_out/prof_pmc1 ...
+
+With --workload it also writes traffic_NAME.json next to the first directory: HBM-side bytes per launch of the
+named kernels (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes; FETCH_SIZE counts 128-byte requests as 64 bytes on
+gfx950), the table bench.py's `roofline.traffic` is read from once merged into profiles/rNN/traffic.json.
 """
+import json
 import csv
 import glob
 import os
@@ -16,7 +21,16 @@ def short(name):
     return name[:70]
 
 
+# kernels whose traffic is tabulated: short label -> substring of the (shortened) kernel name
+TRAFFIC_KERNELS = {"fc1": "gemm_bf16_pp<1, 0>", "qkv_proj": "gemm_bf16_pp<3, 0>", "attention": "attention_fwd<",
+                   "layernorm": "layernorm_rows<"}
+
+
 def main(dirs):
+    workload = None
+    if dirs and dirs[0] == "--workload":
+        workload, dirs = dirs[1], dirs[2:]
+    counters = defaultdict(dict)
     for d in dirs:
         for path in sorted(glob.glob(os.path.join(d, "**", "*.csv"), recursive=True)):
             base = os.path.basename(path)
@@ -38,7 +52,19 @@ def main(dirs):
                     line = "  " + f"{k:70s}"
                     for c, v in sorted(cs.items()):
                         line += f" {c}={sum(v) / len(v):.4g}"
+                        counters[k][c] = sum(v) / len(v)
                     print(line)
+    if workload:
+        table = {}
+        for label, pat in TRAFFIC_KERNELS.items():
+            for k, cs in counters.items():
+                if pat in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+                    table[label] = {"kernel": k, "fetch_kib": cs["FETCH_SIZE"], "write_kib": cs["WRITE_SIZE"],
+                                    "hbm_bytes": (2 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024}
+        path = os.path.join(os.path.dirname(os.path.normpath(dirs[0])), f"traffic_{workload}.json")
+        with open(path, "w") as f:
+            json.dump({workload: table}, f, indent=1)
+        print(f"== wrote {path}")
 
 
 if __name__ == "__main__":

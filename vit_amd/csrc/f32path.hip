@@ -142,8 +142,77 @@ __global__ __launch_bounds__(256) void gemm_f32_128x128(const F32GemmArgs p) {
         }
 }
 
+// Few rows (the head: one row per image): the 128 x 128 tiles would leave all but a dozen CUs idle.  Here a
+// wave computes 16 rows x 32 columns straight from global memory (both operands are L2-resident at these
+// sizes) on v_mfma_f32_16x16x4_f32; a lane loads 4 consecutive k of its row per 16-k step and feeds them to 4
+// MFMAs (the k order inside a step is permuted identically for both operands).  Operands swapped (MFMA row =
+// n), so a lane ends with 4 consecutive n of one row m.  K % 4 == 0.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_rows(const F32GemmArgs p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int m0 = blockIdx.y * 16, n0 = (blockIdx.x * 4 + wave) * 32;
+    if (n0 >= p.N) return;
+    int am = m0 + fr;
+    am = am < p.M ? am : p.M - 1;
+    const float* ap = p.A + (size_t)am * p.K + fq * 4;
+    const float* wp[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        int wr = n0 + nt * 16 + fr;
+        wr = wr < p.N ? wr : p.N - 1;
+        wp[nt] = p.W + (size_t)wr * p.K + fq * 4;
+    }
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    auto step = [&](const f32x4& a, const f32x4& w0, const f32x4& w1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[j], a[j], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[j], a[j], acc[1], 0, 0, 0);
+        }
+    };
+    int k = 0;
+    for (; k + 64 <= p.K; k += 64) {              // four 16-k steps, their 12 loads in flight together
+        f32x4 a[4], w0[4], w1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = *reinterpret_cast<const f32x4*>(ap + k + u * 16);
+            w0[u] = *reinterpret_cast<const f32x4*>(wp[0] + k + u * 16);
+            w1[u] = *reinterpret_cast<const f32x4*>(wp[1] + k + u * 16);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) step(a[u], w0[u], w1[u]);
+    }
+    for (; k < p.K; k += 16) {
+        const bool ok = k + fq * 4 < p.K;
+        step(ok ? *reinterpret_cast<const f32x4*>(ap + k) : zero, ok ? *reinterpret_cast<const f32x4*>(wp[0] + k) : zero,
+             ok ? *reinterpret_cast<const f32x4*>(wp[1] + k) : zero);
+    }
+    const int m = m0 + fr;
+    if (m >= p.M) return;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + nt * 16 + fq * 4 + j;
+            if (n >= p.N) continue;
+            float v = acc[nt][j] + (p.bias ? p.bias[n] : 0.f);
+            if constexpr (EPI == F32_TANH) v = tanhf(v);
+            p.out[(size_t)m * p.N + n] = v;
+        }
+}
+
 template <int EPI, bool GATHER>
 static hipError_t launch_f32(const F32GemmArgs& a, hipStream_t s) {
+    if constexpr (!GATHER && (EPI == F32_BIAS || EPI == F32_TANH)) {
+        if (a.M <= 1024 && a.K % 4 == 0 && (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 &&
+            (reinterpret_cast<uintptr_t>(a.W) & 15) == 0) {
+            dim3 grid((a.N + 127) / 128, (a.M + 15) / 16);
+            hipLaunchKernelGGL((gemm_f32_rows<EPI>), grid, dim3(256), 0, s, a);
+            return hipGetLastError();
+        }
+    }
     dim3 grid((a.N + FBN - 1) / FBN, (a.M + FBM - 1) / FBM);
     hipLaunchKernelGGL((gemm_f32_128x128<EPI, GATHER>), grid, dim3(256), 0, s, a);
     return hipGetLastError();

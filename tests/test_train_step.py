@@ -246,8 +246,9 @@ def test_gpu_input_gradient_gemm_with_activation_derivative(M, N, K, act):
         d = 1 - a * a
     want = prod * d
     err = (out.double() - want).abs()
-    # one bf16 rounding of the result, the product's own rounding boundary, and 2e-6 for the erf approximation
-    tol = want.abs() * 2 ** -7 + prod.abs() * 2 ** -7 * d.abs() + 1e-5
+    # one bf16 rounding of the result, the product's own rounding boundary, and the derivative's approximation
+    # (GELU' uses the polynomial Phi of the forward epilogue: 3.3e-4 absolute)
+    tol = want.abs() * 2 ** -7 + prod.abs() * 2 ** -7 * d.abs() + prod.abs() * (4e-4 if act == "gelu" else 0) + 1e-5
     assert bool((err <= tol).all()), f"max excess {(err - tol).max():.3e}"
     assert torch.isfinite(out).all()
 

@@ -32,7 +32,9 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, const f32x4& a
     float v0 = acc[0] + bias4[0], v1 = acc[1] + bias4[1], v2 = acc[2] + bias4[2], v3 = acc[3] + bias4[3];
     if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_BIAS_TANH_BF16) {
         if constexpr (EPI == EPI_BIAS_GELU_BF16) {
-            v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
+            f32x2 g01 = {v0, v1}, g23 = {v2, v3};              // the polynomial every GEMM kernel of the library uses
+            gelu_erf_x4(g01, g23);
+            v0 = g01[0]; v1 = g01[1]; v2 = g23[0]; v3 = g23[1];
         }
         if constexpr (EPI == EPI_BIAS_TANH_BF16) {
             v0 = tanhf(v0); v1 = tanhf(v1); v2 = tanhf(v2); v3 = tanhf(v3);
@@ -312,13 +314,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_small(const GemmArgs p) {
             const int n = n0 + nt * 16 + fq * 4 + j;
             if (n >= p.N) continue;
             float v = acc[nt][j] + (p.bias ? p.bias[n] : 0.f);
-            if constexpr (EPI == EPI_BIAS_GELU_BF16) v = gelu_erf(v);
+            if constexpr (EPI == EPI_BIAS_GELU_BF16) {
+                // the same polynomial as the tiled kernels' epilogue, so that a row's activations do not
+                // depend on which kernel the batch size selects
+                f32x2 g0 = {v, 0.f}, g1 = {0.f, 0.f};
+                gelu_erf_x4(g0, g1);
+                v = g0[0];
+            }
             if constexpr (EPI == EPI_BIAS_TANH_BF16) v = tanhf(v);
             const size_t off = (size_t)m * p.ldo + n;
             if constexpr (EPI == EPI_MUL_DGELU_BF16 || EPI == EPI_MUL_DTANH_BF16) {
                 // the product rounded to bf16 (what a bf16 matmul hands autograd) times the derivative at aux
                 const float ax = (float)reinterpret_cast<const bf16_t*>(p.aux)[off];
-                const float d = EPI == EPI_MUL_DGELU_BF16 ? dgelu_erf(ax) : fmaf(-ax, ax, 1.0f);
+                const float d = EPI == EPI_MUL_DGELU_BF16 ? dgelu_erf_x2(f32x2{ax, 0.f})[0] : fmaf(-ax, ax, 1.0f);
                 v = (float)(bf16_t)v * d;
             }
             if constexpr (EPI == EPI_BIAS_F32) {

@@ -126,11 +126,11 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
                     // autograd computes as gelu_backward / tanh_backward on the bf16 matmul output
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float a0 = bf16_lo(auxv[i][j]), a1 = bf16_hi(auxv[i][j]);
-                        float d0, d1;
-                        if constexpr (EPI == EPI_MUL_DGELU_BF16) { d0 = dgelu_erf(a0); d1 = dgelu_erf(a1); }
-                        else { d0 = fmaf(-a0, a0, 1.0f); d1 = fmaf(-a1, a1, 1.0f); }
-                        v[j] = pack_bf16(bf16_lo(v[j]) * d0, bf16_hi(v[j]) * d1);
+                        const f32x2 ax = {bf16_lo(auxv[i][j]), bf16_hi(auxv[i][j])};
+                        f32x2 d;
+                        if constexpr (EPI == EPI_MUL_DGELU_BF16) d = dgelu_erf_x2(ax);
+                        else d = 1.0f - ax * ax;
+                        v[j] = pack_bf16(bf16_lo(v[j]) * d[0], bf16_hi(v[j]) * d[1]);
                     }
                 }
                 const int lr = pass * 32 + r;                     // row inside the wave's sub-tile

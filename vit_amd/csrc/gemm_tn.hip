@@ -18,8 +18,8 @@
 //
 // 8 waves, wave (wm, wn) owns 128 m x 64 n of the tile (8 x 4 MFMA tiles, 128 accumulator registers).
 // Two LDS stages; per K tile: wait for this wave's DMA, barrier, issue the next K tile's DMA into the other
-// stage, then for each of the two k-steps 24 transposed reads and 32 MFMA.  The transposed reads are
-// inline asm with their own lgkmcnt waits: issued through the builtin, the compiler would put
+// stage, then 16 steps of 4 MFMA whose transposed reads run two steps ahead behind counted lgkmcnt waits.
+// The transposed reads are inline asm: issued through the builtin, the compiler would put
 // s_waitcnt vmcnt(0) in front of them while the next tile's LDS-DMA is in flight.
 #include <type_traits>
 
@@ -37,7 +37,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_partial(const bf16_t* __restri
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_n = N >> 8, tiles_m = M >> 8;
-    int idx = blockIdx.x;
+    // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): renumber them so that an XCD owns
+    // a contiguous run of (split, tile) ids.  The ~32 workgroups it runs at a time then belong to one k range:
+    // a K tile of G is fetched once for the tiles_n workgroups that read it and a K tile of X once for tiles_m,
+    // instead of each operand coming tiles_n / tiles_m times from beyond L2.
+    int idx;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x;
+        const int q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
+        idx = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+    }
     const int tn = idx % tiles_n;
     idx /= tiles_n;
     const int tm = idx % tiles_m;
@@ -60,16 +69,22 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_partial(const bf16_t* __restri
     const char* g_base = reinterpret_cast<const char*>(G) + (size_t)kt0 * 64 * ldg * 2;
     const char* x_base = reinterpret_cast<const char*>(X) + (size_t)kt0 * 64 * ldx * 2;
     const size_t g_step = (size_t)64 * ldg * 2, x_step = (size_t)64 * ldx * 2;
-    auto issue = [&](int stage, int kt) {
-        const char* gs = g_base + kt * g_step;
-        const char* xs = x_base + kt * x_step;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
+    // piece i (0..7) of this wave's share of K tile kt: i < 4 a G piece, else an X piece
+    auto issue_piece = [&](int stage, int kt, auto ic) {
+        constexpr int i = decltype(ic)::value & 3;
+        if constexpr (decltype(ic)::value < 4) {
             char* dg = smem + stage * kTnStage + (wave * 4 + i) * 1024;
+            __builtin_amdgcn_global_load_lds((gbl_void*)(g_base + kt * g_step + g_off[i]), (lds_void*)dg, 16, 0, 0);
+        } else {
             char* dx = smem + 2 * kTnStage + stage * kTnStage + (wave * 4 + i) * 1024;
-            __builtin_amdgcn_global_load_lds((gbl_void*)(gs + g_off[i]), (lds_void*)dg, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_void*)(xs + x_off[i]), (lds_void*)dx, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(x_base + kt * x_step + x_off[i]), (lds_void*)dx, 16, 0, 0);
         }
+    };
+    auto issue = [&](int stage, int kt) {
+        issue_piece(stage, kt, std::integral_constant<int, 0>{}); issue_piece(stage, kt, std::integral_constant<int, 4>{});
+        issue_piece(stage, kt, std::integral_constant<int, 1>{}); issue_piece(stage, kt, std::integral_constant<int, 5>{});
+        issue_piece(stage, kt, std::integral_constant<int, 2>{}); issue_piece(stage, kt, std::integral_constant<int, 6>{});
+        issue_piece(stage, kt, std::integral_constant<int, 3>{}); issue_piece(stage, kt, std::integral_constant<int, 7>{});
     };
 
     // ---- fragment addresses: lane (q = lane / 16: the 8 k of a k-step, tq: row within 4, tp: 8-byte piece)
@@ -90,37 +105,56 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_partial(const bf16_t* __restri
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // one k-step (32 k) of the K tile in `stage`: fragments = [k 8q..8q+3 | k 8q+4..8q+7] of the lane's column
-    auto k_step = [&](auto stage_c, auto kk_c) {
-        constexpr int off = decltype(stage_c)::value * kTnStage + decltype(kk_c)::value * 32 * 512;
-        bf16x4 gl[8], gh[8], xl[4], xh[4];
+    // A K tile is 16 steps (t = 8 kk + j: k-step kk, m-tile j) of 4 MFMA each.  The fragments of step t + 2
+    // (2 transposed reads for the G fragment, and 8 for the X fragments when t + 2 opens a k-step) are
+    // requested before the MFMAs of step t, and the wait in front of step t is counted: it leaves the reads
+    // issued after G(t) in flight (LDS returns in order), so the LDS latency hides under the matrix work.
+    bf16x4 xl[2][4], xh[2][4];         // X fragments of the two k-steps: [k 8q..8q+3 | k 8q+4..8q+7] of the lane's column
+    bf16x4 gl[3], gh[3];               // ring of G fragments: step t uses slot t % 3
+    auto rd_x = [&](auto stage_c, auto kk_c) {
+        constexpr int kk = decltype(kk_c)::value;
+        constexpr int off = decltype(stage_c)::value * kTnStage + kk * 32 * 512;
+        auto& xl_ = xl; auto& xh_ = xh; auto& xa_ = xa;         // named outside the asm operands: a generic lambda captures only what it names there
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xl[j]) : "v"(xa[j]), "n"(off));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xh[j]) : "v"(xa[j]), "n"(off + 4 * 512));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xl_[kk][j]) : "v"(xa_[j]), "n"(off));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xh_[kk][j]) : "v"(xa_[j]), "n"(off + 4 * 512));
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(gl[j]) : "v"(ga[j]), "n"(off));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(gh[j]) : "v"(ga[j]), "n"(off + 4 * 512));
+    };
+    auto rd_g = [&](auto stage_c, auto t_c) {
+        constexpr int t = decltype(t_c)::value;
+        constexpr int off = decltype(stage_c)::value * kTnStage + (t >> 3) * 32 * 512;
+        auto& gl_ = gl; auto& gh_ = gh; auto& ga_ = ga;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(gl_[t % 3]) : "v"(ga_[t & 7]), "n"(off));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(gh_[t % 3]) : "v"(ga_[t & 7]), "n"(off + 4 * 512));
+    };
+    auto step = [&](auto stage_c, auto t_c, bool more, int kt) {
+        constexpr int t = decltype(t_c)::value, kk = t >> 3, j = t & 7;
+        // the next K tile's LDS-DMA, one instruction per step of the first k-step: issued in one burst behind the
+        // barrier it would hold every wave's matrix work back for its whole issue time
+        if constexpr (t < 8) {
+            if (more) issue_piece(decltype(stage_c)::value ^ 1, kt + 1, t_c);
         }
+        if constexpr (t + 2 < 16) {
+            if constexpr (((t + 2) & 7) == 0) rd_x(stage_c, std::integral_constant<int, (t + 2) / 8>{});
+            rd_g(stage_c, std::integral_constant<int, t + 2>{});
+        }
+        // reads issued after G(t): G(t+1), G(t+2), and the X fragments of the next k-step if it opens at t+1 or t+2
+        constexpr int after = (t + 1 < 16 ? 2 + (((t + 1) & 7) == 0 ? 8 : 0) : 0) +
+                              (t + 2 < 16 ? 2 + (((t + 2) & 7) == 0 ? 8 : 0) : 0);
         // the wait carries the fragment registers as operands, so the MFMAs below cannot move above it
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(xl[0]), "+v"(xl[1]), "+v"(xl[2]), "+v"(xl[3]), "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]));
-        asm volatile("" : "+v"(gl[0]), "+v"(gl[1]), "+v"(gl[2]), "+v"(gl[3]), "+v"(gl[4]), "+v"(gl[5]), "+v"(gl[6]), "+v"(gl[7]));
-        asm volatile("" : "+v"(gh[0]), "+v"(gh[1]), "+v"(gh[2]), "+v"(gh[3]), "+v"(gh[4]), "+v"(gh[5]), "+v"(gh[6]), "+v"(gh[7]));
-        bf16x8 xf[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xf[i] = __builtin_shufflevector(xl[i], xh[i], 0, 1, 2, 3, 4, 5, 6, 7);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const bf16x8 gf = __builtin_shufflevector(gl[j], gh[j], 0, 1, 2, 3, 4, 5, 6, 7);
-            // MFMA row index = n, column index = m: a lane ends up with 4 consecutive n of one row m
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], gf, acc[j][i], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(gl[t % 3]), "+v"(gh[t % 3]) : "n"(after));
+        if constexpr (j == 0) {
+            asm volatile("" : "+v"(xl[kk][0]), "+v"(xl[kk][1]), "+v"(xl[kk][2]), "+v"(xl[kk][3]), "+v"(xh[kk][0]), "+v"(xh[kk][1]),
+                              "+v"(xh[kk][2]), "+v"(xh[kk][3]));
         }
-        __builtin_amdgcn_s_setprio(0);
+        const bf16x8 gf = __builtin_shufflevector(gl[t % 3], gh[t % 3], 0, 1, 2, 3, 4, 5, 6, 7);
+        // MFMA row index = n, column index = m: a lane ends up with 4 consecutive n of one row m
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16x8 xf = __builtin_shufflevector(xl[kk][i], xh[kk][i], 0, 1, 2, 3, 4, 5, 6, 7);
+            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, gf, acc[j][i], 0, 0, 0);
+        }
     };
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
@@ -128,9 +162,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_partial(const bf16_t* __restri
         constexpr int stage = decltype(stage_c)::value;
         __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): this wave's pieces of K tile kt have landed
         __builtin_amdgcn_s_barrier();                          // everyone's have; everyone is done with the other stage
-        if (kt + 1 < ktiles) issue(stage ^ 1, kt + 1);
-        k_step(stage_c, C0{});
-        k_step(stage_c, C1{});
+        const bool more = kt + 1 < ktiles;
+        rd_x(stage_c, C0{});
+        rd_g(stage_c, C0{});
+        rd_g(stage_c, C1{});
+#define VITK_TN_STEP(T) step(stage_c, std::integral_constant<int, T>{}, more, kt);
+        VITK_TN_STEP(0) VITK_TN_STEP(1) VITK_TN_STEP(2) VITK_TN_STEP(3) VITK_TN_STEP(4) VITK_TN_STEP(5) VITK_TN_STEP(6) VITK_TN_STEP(7)
+        VITK_TN_STEP(8) VITK_TN_STEP(9) VITK_TN_STEP(10) VITK_TN_STEP(11) VITK_TN_STEP(12) VITK_TN_STEP(13) VITK_TN_STEP(14) VITK_TN_STEP(15)
+#undef VITK_TN_STEP
     };
 
     if (ktiles > 0) issue(0, 0);

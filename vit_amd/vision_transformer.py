@@ -91,9 +91,21 @@ class VisionTransformer(nn.Module):
             ws = self._ws[key] = Workspace(device, B, N, D, H, M, self.num_classes, fp32=self.precision == "fp32")
         return ws
 
+    def invalidate_weight_cache(self):
+        """Re-derive the kernel-ready weight copies at the next forward.  Needed only after parameters were
+        changed through `.data` (`p.data.copy_()`, `p.data.mul_()`: weight-averaging helpers, some third-party
+        optimizers), which the parameter's version counter does not see; `optimizer.step()`, `load_state_dict`
+        and in-place ops on the parameter itself are detected automatically."""
+        self._cache.invalidate()
+
     def forward(self, x):
         if not x.is_cuda:
             raise VitkError("VisionTransformer.forward needs a CUDA/HIP tensor: this path has no CPU fallback")
+        # every kernel is launched on the current stream of the current device: make that the input's device
+        with torch.cuda.device(x.device):
+            return self._forward(x)
+
+    def _forward(self, x):
         if x.dim() != 4 or x.shape[1] != 3:
             raise VitkError(f"expected images [B,3,H,W], got {tuple(x.shape)}")
         if self.training and self._p_dropout > 0.:

@@ -254,7 +254,7 @@ def main():
         timer.enabled = False
     if not torch.isfinite(y).all():
         raise SystemExit("non-finite logits")
-    dt = vdist.max_over_ranks(dt, device=dev if (world > 1 and not share) else "cpu")
+    dt = vdist.max_over_ranks(dt, device=dev if (torch.distributed.is_initialized() and not share) else "cpu")
 
     if rank == 0:
         F = flops_per_image(cfg, a.img_size)
@@ -294,7 +294,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline and a.mode == "fwd":
             out["cpu_baseline"] = cpu_baseline(a.arch, a.img_size, sd, 32 if a.img_size <= 224 else 8)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         vdist.barrier()
         torch.distributed.destroy_process_group()
 

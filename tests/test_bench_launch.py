@@ -5,6 +5,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -35,3 +37,16 @@ def test_failed_rank_gives_non_zero_exit():
     r = _run("--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline")
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+
+@pytest.mark.gpu
+def test_rccl_group_initialises_and_reduces_on_the_gpu_with_one_rank():
+    """The multi-GPU launch's RCCL path (process group bound to the rank's GPU, barrier, max-reduction on the
+    device) on a one-GPU box: a lone rank with the group forced on.  torch.distributed's "nccl" backend is RCCL."""
+    r = _run("--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline",
+             env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533",
+                  "VIT_AMD_FORCE_GROUP": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["value"] > 0

@@ -181,3 +181,21 @@ def test_whole_pool_against_reference_logits(name):
     assert err.max() <= POOL_TOL.get(name, TOL_BF16), err
     assert same[decided].all()
     assert decided.sum() >= len(err) // 3
+
+
+def test_data_updates_need_an_explicit_cache_invalidation():
+    """In-place updates through `.data` do not move a parameter's version counter, so the bf16 weight copies go
+    stale until `invalidate_weight_cache()`; updates of the parameter itself are seen automatically."""
+    meta, g = load_golden("s16_224_ref")
+    cfg, sd, x = golden_inputs(meta)
+    m = build_model("s16", 224, sd, DEV)
+    xd = x[:2].to(DEV)
+    with torch.no_grad():
+        y0 = m(xd).clone()
+        m.encoder.blocks[0].mlp.fc1.weight.data.mul_(0.5)
+        assert torch.equal(m(xd), y0)                 # stale copies: documented limitation
+        m.invalidate_weight_cache()
+        y1 = m(xd)
+        assert not torch.equal(y1, y0)
+        m.encoder.blocks[0].mlp.fc1.weight.mul_(2.0)  # an in-place op on the parameter is detected by itself
+        assert torch.allclose(m(xd), y0, atol=2e-3)

@@ -30,20 +30,30 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # VIT_AMD_FORCE_GROUP=1 creates the process group even for a lone rank (a one-GPU box can then exercise the
+    # RCCL initialisation, barrier and reduction that a multi-GPU launch goes through)
+    force = os.environ.get("VIT_AMD_FORCE_GROUP") == "1" and "WORLD_SIZE" in os.environ
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
+            # bind the communicator to this rank's GPU: barriers and reductions then never have to guess a device
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
 
 def barrier():
     if dist.is_initialized():
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def max_over_ranks(value, device="cpu"):

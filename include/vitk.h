@@ -198,6 +198,14 @@ int64_t vitk_gemm_tn_workspace(int M, int N, int R);
 int vitk_gemm_tn(const void* G, const void* X, float* C, float* workspace, int64_t workspace_floats, int M, int N,
                  int R, void* stream);
 
+/* vitk_gemm_tn that also returns the layer's bias gradient from the same pass over G: colsum f32 [M] =
+ * sum_r G[r][m] (what autograd computes for the bias of nn.Linear at models/transformer.py:15,17,36,38), with f32
+ * accumulation on the matrix pipe and partial vectors added in a fixed order.  Workspace:
+ * vitk_gemm_tn_colsum_workspace() floats (the partial tiles, then the partial vectors). */
+int64_t vitk_gemm_tn_colsum_workspace(int M, int N, int R);
+int vitk_gemm_tn_colsum(const void* G, const void* X, float* C, float* colsum, float* workspace, int64_t workspace_floats,
+                        int M, int N, int R, void* stream);
+
 /* vitk_attention for the training step: additionally writes lse f32 [batch, heads, ntok], the log2 of each query
  * row's softmax denominator in units of scores * scale * log2(e), which vitk_attention_backward needs. */
 int vitk_attention_lse(const void* q, const void* k, const void* v, void* ctx, float* lse, int batch, int heads,

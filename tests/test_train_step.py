@@ -160,6 +160,15 @@ def test_gpu_weight_gradient_gemm(R, M, N):
     assert err <= 1e-5 * (R ** 0.5) * 4 + 1e-6, f"max abs error {err:.3e}"
     assert torch.equal(got, ops.gemm_tn(gd, xd))
     assert not ops.gemm_tn_supported(1000, 768, R) and not ops.gemm_tn_supported(768, 768, 100)
+    # the same launch with the bias gradient (column sums of g) fused in: identical product, sums vs fp64
+    cs = torch.full((M,), float("nan"), device="cuda")
+    got2 = ops.gemm_tn(gd, xd, colsum=cs)
+    assert torch.equal(got2, got)
+    cerr = (cs.cpu().double() - g.double().sum(0)).abs().max()
+    assert cerr <= 1e-5 * (R ** 0.5) * 4 + 1e-6, f"column sums: max abs error {cerr:.3e}"
+    cs2 = torch.empty_like(cs)
+    ops.gemm_tn(gd, xd, colsum=cs2)
+    assert torch.equal(cs, cs2)
 
 
 @pytest.mark.gpu

@@ -32,18 +32,22 @@ def _operand(g, cd):
     return g if g.dtype == cd else g.to(cd)
 
 
-def _weight_grad(g, a):
-    """f32 [out, in] = g^T a for g [rows, out], a [rows, in]: the HIP split-k kernel on the rows that fill whole
-    64-row K tiles (bf16, out and in multiples of 256), a small library product for the remainder."""
+def _weight_grad(g, a, bias=None):
+    """(f32 [out, in] = g^T a, bias gradient or None) for g [rows, out], a [rows, in]: the HIP split-k kernel on the
+    rows that fill whole 64-row K tiles (bf16, out and in multiples of 256), which sums g's columns in the same pass
+    when the layer has a bias; a small library product for the remaining rows."""
     g, a = g.contiguous(), a.contiguous()
     rows = g.shape[0]
     r64 = rows - rows % 64
     if g.dtype == torch.bfloat16 and r64 > 0 and ops.gemm_tn_supported(g.shape[1], a.shape[1], r64):
-        gw = ops.gemm_tn(g[:r64], a[:r64])
+        gb = None if bias is None else torch.empty(g.shape[1], dtype=torch.float32, device=g.device)
+        gw = ops.gemm_tn(g[:r64], a[:r64], colsum=gb)
         if r64 < rows:
             gw += (g[r64:].t() @ a[r64:]).float()
-        return gw
-    return (g.t() @ a).float()
+            if gb is not None:
+                gb += g[r64:].sum(0, dtype=torch.float32)
+        return gw, (None if gb is None else gb.to(bias.dtype))
+    return (g.t() @ a).float(), _bias_grad(g, bias)
 
 
 def _bias_grad(g, bias):
@@ -76,8 +80,8 @@ def _input_grad(g, w_cd, wt, aux=None, act=None):
 def _linear_backward(g_pre, a, w_cd, wt, weight, bias, aux=None, act=None):
     """g_pre [rows, out] in cd -> (grad of a [rows, in] in cd (through `act` if given), grad weight, grad bias)."""
     ga = _input_grad(g_pre, w_cd, wt, aux, act)
-    gw = _weight_grad(g_pre, a).to(weight.dtype)
-    return ga, gw, _bias_grad(g_pre, bias)
+    gw, gb = _weight_grad(g_pre, a, bias)
+    return ga, gw.to(weight.dtype), gb
 
 
 def _ln_backward(x, weight, bias, eps, g, g_skip, want16):
@@ -332,7 +336,7 @@ class PatchEmbedFn(torch.autograd.Function):
         cols = img[:, :, :gh * P, :gw_ * P].reshape(B, 3, gh, P, gw_, P).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw_, 3 * P * P)
         gp = g[:, 1:, :]
         gp_cd = gp.reshape(B * (N - 1), D).to(img.dtype)
-        gw = _weight_grad(gp_cd, cols)
+        gw, _ = _weight_grad(gp_cd, cols)
         gb = gp.sum((0, 1))
         gc = g[:, 0, :].sum(0).view(1, 1, D)
         gpos = g.sum(0, keepdim=True)

@@ -7,6 +7,10 @@
 // range is split over S workgroups per tile, each writes an f32 partial tile, and a second kernel adds the
 // S partials in a fixed order (reproducible; no atomics).
 //
+// COLSUM: the column sums of G (the bias gradient of the same layer, sum_k G[k][m]) come out of the same pass:
+// the workgroups of n-tile 0 multiply every G fragment once more, with an all-ones operand, wave (wm, wn) for
+// the m-tiles 2 wn and 2 wn + 1 of its 8 (2 more MFMA per 32), and write a partial vector per split.
+//
 // Both operands are k-major in memory, the wrong way round for an MFMA fragment (8 consecutive k per
 // lane).  A K tile (64 rows of k) of each operand goes to LDS as it lies in memory (LDS-DMA, 512-byte
 // rows of 256 m or n), and the fragments come out through ds_read_b64_tr_b16, which hands each lane of a
@@ -30,9 +34,10 @@ namespace vitk {
 constexpr int kTnStage = 64 * 512;            // one operand K tile: 64 k-rows x 256 columns bf16
 constexpr int kTnLds = 4 * kTnStage;          // [G stage 0][G stage 1][X stage 0][X stage 1]
 
+template <bool COLSUM>
 __global__ __launch_bounds__(512, 2) void gemm_tn_partial(const bf16_t* __restrict__ G, const bf16_t* __restrict__ X,
-                                                          float* __restrict__ part, int M, int N, int ldg, int ldx,
-                                                          int ktiles_total, int splits) {
+                                                          float* __restrict__ part, float* __restrict__ colsum_part,
+                                                          int M, int N, int ldg, int ldx, int ktiles_total, int splits) {
     __shared__ __attribute__((aligned(1024))) char smem[kTnLds];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -104,6 +109,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_partial(const bf16_t* __restri
     for (int j = 0; j < 8; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // COLSUM: the m-tile pair whose column sums this wave accumulates (none outside n-tile 0)
+    const int cs_j0 = (COLSUM && tn == 0) ? 2 * wn : -2;
+    f32x4 cs_acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const u32x4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
 
     // A K tile is 16 steps (t = 8 kk + j: k-step kk, m-tile j) of 4 MFMA each.  The fragments of step t + 2
     // (2 transposed reads for the G fragment, and 8 for the X fragments when t + 2 opens a k-step) are
@@ -155,6 +165,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_partial(const bf16_t* __restri
             const bf16x8 xf = __builtin_shufflevector(xl[kk][i], xh[kk][i], 0, 1, 2, 3, 4, 5, 6, 7);
             acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, gf, acc[j][i], 0, 0, 0);
         }
+        if constexpr (COLSUM) {
+            // every row of the result holds sum_k G[k][m] for the lane's column m
+            if ((j & ~1) == cs_j0) cs_acc[j & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, gf, cs_acc[j & 1], 0, 0, 0);
+        }
     };
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
@@ -184,16 +198,33 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_partial(const bf16_t* __restri
     for (int j = 0; j < 8; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(out + (size_t)j * 16 * N + i * 16) = acc[j][i];
+    if constexpr (COLSUM) {
+        if (cs_j0 >= 0 && lane < 16) {
+            float* cs = colsum_part + (size_t)split * M + m0 + wm * 128 + cs_j0 * 16 + lane;
+            cs[0] = cs_acc[0][0];
+            cs[16] = cs_acc[1][0];
+        }
+    }
 }
 
 // C = sum over the S partials, in split order
+// (and, with colsum_part, the column-sum vector [M] = sum over the S partial vectors; the last blocks take it)
 __global__ __launch_bounds__(256) void gemm_tn_reduce(const float* __restrict__ part, float* __restrict__ C, size_t mn4,
-                                                      int splits) {
+                                                      int splits, const float* __restrict__ colsum_part,
+                                                      float* __restrict__ colsum, int m4) {
     const size_t stride = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < mn4; i += stride) {
         f32x4 a = reinterpret_cast<const f32x4*>(part)[i];
         for (int s = 1; s < splits; ++s) a = a + reinterpret_cast<const f32x4*>(part)[(size_t)s * mn4 + i];
         reinterpret_cast<f32x4*>(C)[i] = a;
+    }
+    if (colsum_part) {
+        const int i = (int)(gridDim.x - 1 - blockIdx.x) * 256 + (int)threadIdx.x;
+        if (i < m4) {
+            f32x4 a = reinterpret_cast<const f32x4*>(colsum_part)[i];
+            for (int s = 1; s < splits; ++s) a = a + reinterpret_cast<const f32x4*>(colsum_part)[(size_t)s * m4 + i];
+            reinterpret_cast<f32x4*>(colsum)[i] = a;
+        }
     }
 }
 
@@ -207,19 +238,27 @@ int gemm_tn_splits(int M, int N, int R) {
     return s;
 }
 
-hipError_t launch_gemm_tn(const void* G, const void* X, float* C, float* part, int M, int N, int R, int ldg, int ldx,
-                          hipStream_t s) {
+// colsum (optional): f32 [M] = column sums of G; with splits > 1 its partial vectors follow the splits * M * N
+// floats of partial tiles in `part`
+hipError_t launch_gemm_tn(const void* G, const void* X, float* C, float* colsum, float* part, int M, int N, int R,
+                          int ldg, int ldx, hipStream_t s) {
     const int splits = gemm_tn_splits(M, N, R);
     if (splits <= 0) return hipErrorInvalidValue;
     const int grid = (M >> 8) * (N >> 8) * splits;
-    hipLaunchKernelGGL(gemm_tn_partial, dim3(grid), dim3(512), 0, s, reinterpret_cast<const bf16_t*>(G),
-                       reinterpret_cast<const bf16_t*>(X), splits == 1 ? C : part, M, N, ldg, ldx, R / 64, splits);
+    float* cs_part = colsum ? (splits == 1 ? colsum : part + (size_t)splits * M * N) : nullptr;
+    if (colsum)
+        hipLaunchKernelGGL(gemm_tn_partial<true>, dim3(grid), dim3(512), 0, s, reinterpret_cast<const bf16_t*>(G),
+                           reinterpret_cast<const bf16_t*>(X), splits == 1 ? C : part, cs_part, M, N, ldg, ldx, R / 64, splits);
+    else
+        hipLaunchKernelGGL(gemm_tn_partial<false>, dim3(grid), dim3(512), 0, s, reinterpret_cast<const bf16_t*>(G),
+                           reinterpret_cast<const bf16_t*>(X), splits == 1 ? C : part, cs_part, M, N, ldg, ldx, R / 64, splits);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || splits == 1) return e;
     const size_t mn4 = (size_t)M * N / 4;
     size_t blocks = (mn4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(gemm_tn_reduce, dim3((unsigned)blocks), dim3(256), 0, s, part, C, mn4, splits);
+    if (blocks < (size_t)(M / 4 + 255) / 256) blocks = (M / 4 + 255) / 256;
+    hipLaunchKernelGGL(gemm_tn_reduce, dim3((unsigned)blocks), dim3(256), 0, s, part, C, mn4, splits, cs_part, colsum, M / 4);
     return hipGetLastError();
 }
 

@@ -61,7 +61,7 @@ int dense(const char* name, const void* A, const void* W, const float* bias, con
 
 extern "C" {
 
-int vitk_version(void) { return 4; }
+int vitk_version(void) { return 5; }
 
 const char* vitk_last_error(void) { return g_err; }
 
@@ -341,19 +341,37 @@ int64_t vitk_gemm_tn_workspace(int M, int N, int R) {
     return splits <= 1 ? 0 : (int64_t)splits * M * N;
 }
 
+static int gemm_tn_checked(const char* name, const void* G, const void* X, float* C, float* colsum, float* workspace,
+                           int64_t workspace_floats, int64_t need, int M, int N, int R, void* stream) {
+    if (!G || !X || !C) return fail(VITK_ERR_INVALID, "%s: null pointer", name);
+    if (M <= 0 || N <= 0 || R <= 0 || M % 256 || N % 256 || R % 64)
+        return fail(VITK_ERR_UNSUPPORTED, "%s: M=%d N=%d R=%d (M, N multiples of 256, R of 64)", name, M, N, R);
+    if ((int64_t)R * (M > N ? M : N) * 2 >= ((int64_t)1 << 32))
+        return fail(VITK_ERR_UNSUPPORTED, "%s: operand of 4 GiB or more", name);
+    if (need > 0 && (!workspace || workspace_floats < need))
+        return fail(VITK_ERR_INVALID, "%s: workspace of %lld floats needed", name, (long long)need);
+    if (!aligned16(G) || !aligned16(X) || !aligned16(C) || (workspace && !aligned16(workspace)) || (colsum && !aligned16(colsum)))
+        return fail(VITK_ERR_INVALID, "%s: pointers must be 16-byte aligned", name);
+    return launched(launch_gemm_tn(G, X, C, colsum, workspace, M, N, R, M, N, reinterpret_cast<hipStream_t>(stream)), name);
+}
+
 int vitk_gemm_tn(const void* G, const void* X, float* C, float* workspace, int64_t workspace_floats, int M, int N,
                  int R, void* stream) {
-    if (!G || !X || !C) return fail(VITK_ERR_INVALID, "vitk_gemm_tn: null pointer");
-    if (M <= 0 || N <= 0 || R <= 0 || M % 256 || N % 256 || R % 64)
-        return fail(VITK_ERR_UNSUPPORTED, "vitk_gemm_tn: M=%d N=%d R=%d (M, N multiples of 256, R of 64)", M, N, R);
-    if ((int64_t)R * (M > N ? M : N) * 2 >= ((int64_t)1 << 32))
-        return fail(VITK_ERR_UNSUPPORTED, "vitk_gemm_tn: operand of 4 GiB or more");
-    const int64_t need = vitk_gemm_tn_workspace(M, N, R);
-    if (need > 0 && (!workspace || workspace_floats < need))
-        return fail(VITK_ERR_INVALID, "vitk_gemm_tn: workspace of %lld floats needed", (long long)need);
-    if (!aligned16(G) || !aligned16(X) || !aligned16(C) || (workspace && !aligned16(workspace)))
-        return fail(VITK_ERR_INVALID, "vitk_gemm_tn: pointers must be 16-byte aligned");
-    return launched(launch_gemm_tn(G, X, C, workspace, M, N, R, M, N, reinterpret_cast<hipStream_t>(stream)), "vitk_gemm_tn");
+    return gemm_tn_checked("vitk_gemm_tn", G, X, C, nullptr, workspace, workspace_floats, vitk_gemm_tn_workspace(M, N, R), M, N, R,
+                           stream);
+}
+
+int64_t vitk_gemm_tn_colsum_workspace(int M, int N, int R) {
+    if (M <= 0 || N <= 0 || R <= 0 || M % 256 || N % 256 || R % 64) return -1;
+    const int splits = gemm_tn_splits(M, N, R);
+    return splits <= 1 ? 0 : (int64_t)splits * M * N + (int64_t)splits * M;
+}
+
+int vitk_gemm_tn_colsum(const void* G, const void* X, float* C, float* colsum, float* workspace, int64_t workspace_floats,
+                        int M, int N, int R, void* stream) {
+    if (!colsum) return fail(VITK_ERR_INVALID, "vitk_gemm_tn_colsum: null pointer");
+    return gemm_tn_checked("vitk_gemm_tn_colsum", G, X, C, colsum, workspace, workspace_floats,
+                           vitk_gemm_tn_colsum_workspace(M, N, R), M, N, R, stream);
 }
 
 int vitk_gemm_bias_gelu_dual(const void* A, const void* W, const float* bias, void* pre, void* out, int M, int N, int K,

@@ -51,8 +51,8 @@ hipError_t launch_layernorm_backward(const float* x, int64_t x_row_stride, const
                                      bool g_bf16, const float* add, float* dx, void* dx16, float* dgamma, float* dbeta, float* partials,
                                      int partial_rows, int rows, int D, float eps, hipStream_t s);
 int gemm_tn_splits(int M, int N, int R);
-hipError_t launch_gemm_tn(const void* G, const void* X, float* C, float* part, int M, int N, int R, int ldg, int ldx,
-                          hipStream_t s);
+hipError_t launch_gemm_tn(const void* G, const void* X, float* C, float* colsum, float* part, int M, int N, int R,
+                          int ldg, int ldx, hipStream_t s);
 hipError_t launch_colsum_bf16(const void* G, float* out, float* partials, int partial_rows, int R, int M, hipStream_t s);
 // the library's own partial-sum buffer for vitk_colsum_bf16_static: f32 [kColsumStaticRows, kColsumStaticMaxM]
 // in device memory of the current device (resolved once per device); out may be nullptr (resolve only)

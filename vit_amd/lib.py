@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VITK_LIB") or os.path.join(_HERE, "libvitk.so")
 
 VITK_F32, VITK_BF16 = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int
@@ -42,6 +42,7 @@ SIGNATURES = {
     "vitk_attention_backward": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "vitk_colsum_bf16": [_p, _p, _p, _i, _i, _i, _p],
     "vitk_gemm_tn": [_p, _p, _p, _p, _i64, _i, _i, _i, _p],
+    "vitk_gemm_tn_colsum": [_p, _p, _p, _p, _p, _i64, _i, _i, _i, _p],
     "vitk_layernorm_backward": [_p, _i64, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
     "vitk_gemm_grad_act": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "vitk_init": [],
@@ -50,7 +51,7 @@ SIGNATURES = {
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_TANH = 0, 1, 2, 3      # vitk_gemm_f32 epilogues (include/vitk.h)
 ACT_GELU, ACT_TANH = 0, 1                                    # vitk_gemm_grad_act
 EXPORTS = sorted(list(SIGNATURES) + ["vitk_version", "vitk_last_error", "vitk_set_debug_variant",
-                                    "vitk_gemm_tn_workspace"])
+                                    "vitk_gemm_tn_workspace", "vitk_gemm_tn_colsum_workspace"])
 
 _lib = None
 
@@ -75,8 +76,9 @@ def load():
     lib.vitk_last_error.argtypes = []
     lib.vitk_set_debug_variant.restype = None
     lib.vitk_set_debug_variant.argtypes = [_i, _i]
-    lib.vitk_gemm_tn_workspace.restype = _i64
-    lib.vitk_gemm_tn_workspace.argtypes = [_i, _i, _i]
+    for fn in (lib.vitk_gemm_tn_workspace, lib.vitk_gemm_tn_colsum_workspace):
+        fn.restype = _i64
+        fn.argtypes = [_i, _i, _i]
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = _i

@@ -340,8 +340,9 @@ def gemm_tn_supported(M, N, R):
     return _lib.load().vitk_gemm_tn_workspace(M, N, R) >= 0
 
 
-def gemm_tn(g, x, out=None):
-    """out f32 [M, N] = g^T x for g bf16 [R, M], x bf16 [R, N] (the weight gradient of a Linear layer)."""
+def gemm_tn(g, x, out=None, colsum=None):
+    """out f32 [M, N] = g^T x for g bf16 [R, M], x bf16 [R, N] (the weight gradient of a Linear layer).  With
+    `colsum` (f32 [M]) the same launch also writes the column sums of g (the layer's bias gradient)."""
     L = _lib.load()
     _chk(g, torch.bfloat16, "g")
     _chk(x, torch.bfloat16, "x")
@@ -349,7 +350,7 @@ def gemm_tn(g, x, out=None):
         raise _lib.VitkError(f"gemm_tn: g {tuple(g.shape)}, x {tuple(x.shape)}")
     R, M = g.shape
     N = x.shape[1]
-    need = L.vitk_gemm_tn_workspace(M, N, R)
+    need = (L.vitk_gemm_tn_workspace if colsum is None else L.vitk_gemm_tn_colsum_workspace)(M, N, R)
     if need < 0:
         raise _lib.VitkError(f"gemm_tn: unsupported shape M={M} N={N} R={R} (M, N multiples of 256, R of 64)")
     ws = _tn_workspace.get(g.device)
@@ -358,9 +359,15 @@ def gemm_tn(g, x, out=None):
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=g.device)
     _chk(out, torch.float32, "out")
+    wsp, wsn = (_ptr(ws), ws.numel()) if need > 0 else (None, 0)
     with _span("gemm_tn"):
-        _lib.check(L.vitk_gemm_tn(_ptr(g), _ptr(x), _ptr(out), _ptr(ws) if need > 0 else None, ws.numel() if need > 0 else 0,
-                                  M, N, R, _stream()), L)
+        if colsum is None:
+            _lib.check(L.vitk_gemm_tn(_ptr(g), _ptr(x), _ptr(out), wsp, wsn, M, N, R, _stream()), L)
+        else:
+            _chk(colsum, torch.float32, "colsum")
+            if colsum.numel() != M:
+                raise _lib.VitkError(f"gemm_tn: colsum has {colsum.numel()} elements, expected {M}")
+            _lib.check(L.vitk_gemm_tn_colsum(_ptr(g), _ptr(x), _ptr(out), _ptr(colsum), wsp, wsn, M, N, R, _stream()), L)
     return out
 
 

@@ -489,6 +489,29 @@ static hipError_t attn_launch(const void* q, const void* k, const void* v, void*
 // head in the 160 KiB of LDS (608 tokens at head_dim 64, 288 at head_dim 96)
 int attention_max_tokens(int hd) { return (hd == 64 || hd == 80 || hd == 96) ? 16384 : 0; }
 
+// Waves of a workgroup that owns one head and deals its q-tiles (or, in the backward, its owner-row tiles) to its
+// waves round-robin.  Wave w sits on SIMD w % 4 and takes tiles w, w + c, ...: the launch takes as long as the SIMD
+// with the most tiles (the key loop is bound by vector issue).  Fewest tiles on the busiest SIMD, then fewest rounds
+// (the sequential chain of one wave), then most waves at work (a third wave on a SIMD hides more of the score ->
+// max -> exp -> P.V chain), then fewest idle waves.  Measured at N = 577 (19 q-tiles; 5, 5, 6 tiles on the busiest
+// SIMD): 12 waves 217 us, 8 waves 225, 10 waves 242; N = 485: 12 waves 166, 8 waves 178; N = 401: 12 or 10 waves
+// 132, 7 waves 142.
+int attention_pick_waves(int tiles, int max_waves) {
+    long best = -1;
+    int nw = 4;
+    for (int c : {4, 5, 6, 7, 8, 10, 12}) {
+        if (c > max_waves) continue;
+        int simd[4] = {0, 0, 0, 0};
+        for (int w = 0; w < c && w < tiles; ++w) simd[w & 3] += (tiles - w + c - 1) / c;
+        int crit = simd[0];
+        for (int i = 1; i < 4; ++i) crit = simd[i] > crit ? simd[i] : crit;
+        const int rounds = (tiles + c - 1) / c, active = c < tiles ? c : tiles;
+        const long cost = (((long)crit * 64 + rounds) * 16 + (15 - active)) * 16 + (c - active);
+        if (best < 0 || cost < best) { best = cost; nw = c; }
+    }
+    return nw;
+}
+
 hipError_t launch_attention(const void* q, const void* k, const void* v, void* out, int batch, int heads,
                             int ntok, int hd, float scale, int variant, hipStream_t s, float* lse) {
     if ((hd != 64 && hd != 80 && hd != 96) || ntok < 1) return hipErrorInvalidValue;
@@ -504,16 +527,12 @@ hipError_t launch_attention(const void* q, const void* k, const void* v, void* o
     if (mode == 0 && !fits2) mode = 3;
     const int probe = (variant >> 2) & 7;       // read by diagnostic builds only
     // Waves per workgroup (one 32-row q-tile at a time each).  Resident K/V: one workgroup per head, its
-    // waves take q-tiles round-robin; the width with the best balance (q-tiles / (rounds * waves)), the
-    // larger on ties.  Streamed: one q-tile per wave, fewest workgroups per head, then fewest idle slots.
+    // waves take q-tiles round-robin (the width is chosen below).  Streamed: one q-tile per wave, fewest
+    // workgroups per head, then fewest idle slots.
     int nw = 4;
     if (mode != 2) {
-        long best = -1;
-        for (int c : {4, 5, 6, 7, 8, 10}) {
-            const int rounds = (qtiles + c - 1) / c;
-            const long util = 1000L * qtiles / (rounds * c);
-            if (util >= best) { best = util; nw = c; }
-        }
+        // two resident heads and the output windows: at most 8 waves; 12 are built for head_dim 64 only
+        nw = attention_pick_waves(qtiles, mode == 0 ? 8 : (mode == 3 && hd == 64) ? 12 : 10);
     } else if (qtiles > 4 && qtiles <= 7) {
         nw = 7;
     } else if (qtiles > 7) {
@@ -522,6 +541,10 @@ hipError_t launch_attention(const void* q, const void* k, const void* v, void* o
             const int wgs = (qtiles + c - 1) / c, idle = wgs * c - qtiles;
             if (wgs < best_wgs || (wgs == best_wgs && idle < best_idle)) { best_wgs = wgs; best_idle = idle; nw = c; }
         }
+    }
+    {   // test hook: variant bits 5..8 force the wave count (resident modes: 4..8 or 10; streamed: 4..8)
+        const int forced = (variant >> 5) & 15;
+        if ((forced >= 4 && forced <= 8) || ((forced == 10 || forced == 12) && mode != 2)) nw = forced;
     }
 #define VITK_ATTN_CASE(NWV)                                                                                   \
     case NWV:                                                                                                 \
@@ -548,6 +571,9 @@ hipError_t launch_attention(const void* q, const void* k, const void* v, void* o
             if (mode == 0) return attn_launch<64, 10, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);
             if (mode == 3) return attn_launch<64, 10, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);
             return attn_launch<64, 10, false, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);
+        case 12:      // one resident head per workgroup, head_dim 64 only
+            if (hd == 64 && mode == 3) return attn_launch<64, 12, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);
+            return hipErrorInvalidValue;
     }
 #undef VITK_ATTN_CASE
     return hipErrorInvalidValue;

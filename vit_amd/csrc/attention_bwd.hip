@@ -241,13 +241,7 @@ hipError_t launch_attention_backward(const void* q, const void* k, const void* v
                                      float scale, hipStream_t s) {
     if (hd != 64 || ntok < 1 || ntok > attention_bwd_max_tokens()) return hipErrorInvalidValue;
     const int tiles = (ntok + 31) / 32;
-    int nw = 4;
-    long best = -1;
-    for (int cnd : {4, 5, 6, 7, 8}) {
-        const int rounds = (tiles + cnd - 1) / cnd;
-        const long util = 1000L * tiles / (rounds * cnd);
-        if (util >= best) { best = util; nw = cnd; }
-    }
+    const int nw = attention_pick_waves(tiles, 8);
     switch (nw) {
         case 4: return attn_bwd_launch<4>(q, k, v, o, d_o, lse, dbuf, dqkv, batch, heads, ntok, scale, s);
         case 5: return attn_bwd_launch<5>(q, k, v, o, d_o, lse, dbuf, dqkv, batch, heads, ntok, scale, s);

@@ -64,6 +64,7 @@ hipError_t launch_target_rank(const float* logits, const int64_t* target, int* r
                               hipStream_t s);
 hipError_t launch_pos_embed_scale(const float* in, float* out, int g, int G, int D, hipStream_t s);
 hipError_t launch_cast_f32_bf16(const float* in, void* out, int64_t n, hipStream_t s);
+int attention_pick_waves(int tiles, int max_waves);
 int attention_max_tokens(int hd);
 hipError_t launch_attention(const void* q, const void* k, const void* v, void* out, int batch, int heads,
                             int ntok, int hd, float scale, int variant, hipStream_t s, float* lse = nullptr);

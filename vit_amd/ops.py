@@ -36,6 +36,12 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def _scratch_key(device, *extra):
+    """Key of a cached scratch buffer: one per device AND stream, so that launches queued on two streams of a
+    device never share partial-sum buffers."""
+    return (device, torch.cuda.current_stream(device).cuda_stream) + extra
+
+
 def _chk(t, dtype, name):
     if t is None:
         return
@@ -319,7 +325,7 @@ def layernorm_backward(x, gamma, g, eps, add=None, dx_bf16=None):
     if g.dtype not in (torch.bfloat16, torch.float32) or g.shape != x.shape or x.dim() != 2:
         raise _lib.VitkError(f"layernorm_backward: x {tuple(x.shape)} {x.dtype}, g {tuple(g.shape)} {g.dtype}")
     rows, D = x.shape
-    key = (x.device, D)
+    key = _scratch_key(x.device, D)
     part = _ln_partials.get(key)
     if part is None:
         part = _ln_partials[key] = torch.empty(1024, 2, D, dtype=torch.float32, device=x.device)
@@ -353,9 +359,10 @@ def gemm_tn(g, x, out=None, colsum=None):
     need = (L.vitk_gemm_tn_workspace if colsum is None else L.vitk_gemm_tn_colsum_workspace)(M, N, R)
     if need < 0:
         raise _lib.VitkError(f"gemm_tn: unsupported shape M={M} N={N} R={R} (M, N multiples of 256, R of 64)")
-    ws = _tn_workspace.get(g.device)
+    key = _scratch_key(g.device)
+    ws = _tn_workspace.get(key)
     if need > 0 and (ws is None or ws.numel() < need):
-        ws = _tn_workspace[g.device] = torch.empty(need, dtype=torch.float32, device=g.device)
+        ws = _tn_workspace[key] = torch.empty(need, dtype=torch.float32, device=g.device)
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=g.device)
     _chk(out, torch.float32, "out")
@@ -445,9 +452,10 @@ def colsum(g):
     L = _lib.load()
     _chk(g, torch.bfloat16, "g")
     R, M = g.shape
-    part = _colsum_partials.get(g.device)
+    key = _scratch_key(g.device)
+    part = _colsum_partials.get(key)
     if part is None or part.numel() < 256 * M:
-        part = _colsum_partials[g.device] = torch.empty(256 * max(M, 4096), dtype=torch.float32, device=g.device)
+        part = _colsum_partials[key] = torch.empty(256 * max(M, 4096), dtype=torch.float32, device=g.device)
     out = torch.empty(M, dtype=torch.float32, device=g.device)
     with _span("colsum"):
         _lib.check(L.vitk_colsum_bf16(_ptr(g), _ptr(out), _ptr(part), 256, R, M, _stream()), L)

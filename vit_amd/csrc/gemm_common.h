@@ -76,6 +76,27 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
         } else {
             col_off = (uint32_t)(nw + cc * 8);
         }
+        // AUXMUL: the whole sub-tile's pieces of aux are requested up front (16 loads per lane in flight: one memory
+        // round trip per tile instead of one per pass; the K loop's fragment registers are free here)
+        // (AHEAD == 2; with AHEAD == 1 a pass requests its own pieces: for kernels that hold fragments across the epilogue)
+        constexpr bool AUX_UPFRONT = AUXMUL && AHEAD == 2;
+        u32x4 aux_all[AUX_UPFRONT ? 4 : 1][4];
+        auto load_aux = [&](u32x4 (&dst)[4], int pass) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int row = mw + pass * 32 + i * 8 + rc;
+                row = row < p.M ? row : p.M - 1;         // loads stay in bounds; such rows are not stored
+                dst[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.aux) +
+                                                         ((uint32_t)row * p.ldo + col_off) * 2u);
+            }
+        };
+        if constexpr (AUX_UPFRONT) {
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                if (MASKED && pass * 2 >= my_mt) break;
+                load_aux(aux_all[pass], pass);
+            }
+        }
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
             if (MASKED && pass * 2 >= my_mt) break;
@@ -83,16 +104,8 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
             for (int rep = 0; rep < (DUAL ? 2 : 1); ++rep) {
             const bool gelu_now = EPI == EPI_BIAS_GELU_BF16 || (DUAL && rep == 1);
             char* dst = reinterpret_cast<char*>((DUAL && rep == 0) ? p.out2 : p.out);
-            u32x4 auxv[4];                               // AUXMUL: this pass's pieces of aux, requested before the window trip
-            if constexpr (AUXMUL) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    int row = mw + pass * 32 + i * 8 + rc;
-                    row = row < p.M ? row : p.M - 1;     // loads stay in bounds; such rows are not stored
-                    auxv[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.aux) +
-                                                              ((uint32_t)row * p.ldo + col_off) * 2u);
-                }
-            }
+            u32x4 (&auxv)[4] = aux_all[AUX_UPFRONT ? pass : 0];
+            if constexpr (AUXMUL && !AUX_UPFRONT) load_aux(auxv, pass);
 #pragma unroll
             for (int m2 = 0; m2 < 2; ++m2) {
                 if (MASKED && pass * 2 + m2 >= my_mt) break;

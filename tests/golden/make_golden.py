@@ -245,20 +245,29 @@ def accuracy_fixture():
     print("accuracy", len(cases), "cases")
 
 
-def train_fixture():
+DROPOUT_P, DROPOUT_P_ATTN, DROPOUT_SEED = 0.1, 0.2, 11
+
+
+def train_fixture(dropout=False):
     """Loss, logits and parameter gradients of one training step (main.py:207-218: CrossEntropyLoss, backward)
     of the reference model class on a small configuration with synthetic weights.  Gradients are stored
-    subsampled (every `STRIDE`-th element of the flattened tensor) with each tensor's full L2 norm."""
+    subsampled (every `STRIDE`-th element of the flattened tensor) with each tensor's full L2 norm.
+    dropout=True: the same with dropout / attn_dropout > 0 and torch's CPU generator seeded just before the
+    forward (train_dropout.*), which pins where the Dropout layers sit and the order they draw their masks in."""
     from oracle import train_oracle as to
     cfg = to.SMALL
+    name = "train_dropout" if dropout else "train_small"
+    extra = dict(dropout=DROPOUT_P, attn_dropout=DROPOUT_P_ATTN) if dropout else {}
     sd = synth.synth_state_dict(cfg, to.SMALL_IMG, seed=5, style="perturbed", num_classes=to.SMALL_CLASSES)
     m = ref_vt.VisionTransformer(img_size=to.SMALL_IMG, patches=cfg["patches"], num_classes=to.SMALL_CLASSES,
                                  hidden_size=cfg["hidden_size"], num_layers=cfg["num_layers"],
                                  num_heads=cfg["num_heads"], mlp_ratio=cfg["mlp_ratio"],
-                                 norm=partial(torch.nn.LayerNorm, eps=cfg["eps"])).train()
+                                 norm=partial(torch.nn.LayerNorm, eps=cfg["eps"]), **extra).train()
     m.load_state_dict(sd, strict=True)
     x = synth.synth_images(to.SMALL_BATCH, to.SMALL_IMG, seed=6)
     target = torch.tensor([3, 1, 4, 1, 5, 9])
+    if dropout:
+        torch.manual_seed(DROPOUT_SEED)
     logits = m(x)
     loss = torch.nn.CrossEntropyLoss()(logits, target)
     loss.backward()
@@ -270,16 +279,22 @@ def train_fixture():
         g = p.grad / coef                                                  # undo the clip: store raw gradients
         out["gnorm." + k] = np.array(float(g.norm()))
         out["g." + k] = np_(g.reshape(-1)[::STRIDE])
-    np.savez_compressed(os.path.join(HERE, "train_small.npz"), **out)
-    with open(os.path.join(HERE, "train_small.json"), "w") as f:
-        json.dump({"stride": STRIDE, "seed": 5, "image_seed": 6, "n_params": len(list(m.parameters()))}, f)
-    print("train_small loss %.6f total grad norm %.4f" % (float(loss), float(total)))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    meta = {"stride": STRIDE, "seed": 5, "image_seed": 6, "n_params": len(list(m.parameters()))}
+    if dropout:
+        meta.update(dropout=DROPOUT_P, attn_dropout=DROPOUT_P_ATTN, torch_seed=DROPOUT_SEED)
+    with open(os.path.join(HERE, name + ".json"), "w") as f:
+        json.dump(meta, f)
+    print(name + " loss %.6f total grad norm %.4f" % (float(loss), float(total)))
 
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
     if sys.argv[1:] == ["train"]:
         train_fixture()
+        sys.exit(0)
+    if sys.argv[1:] == ["train_dropout"]:
+        train_fixture(dropout=True)
         sys.exit(0)
     if sys.argv[1:] == ["accuracy"]:
         accuracy_fixture()

@@ -344,6 +344,105 @@ class PatchEmbedFn(torch.autograd.Function):
             None, None, None, None, None, None
 
 
+class LinearFn(torch.autograd.Function):
+    """act(a W^T + b) in cd, act = GELU or none, as its own graph node (no residual, no LayerNorm fused behind it):
+    the building block of the training path with dropout > 0, where a Dropout sits between every Linear layer and
+    whatever follows it (models/transformer.py:21-25,47,69-70)."""
+
+    @staticmethod
+    def forward(ctx, a, weight, bias, w_cd, w_t, gelu):
+        rows, cd = a.shape[0], a.dtype
+        b32 = None if bias is None else bias.detach()
+        out = torch.empty(rows, weight.shape[0], dtype=cd, device=a.device)
+        pre = None
+        if cd == torch.float32:
+            ops.gemm_f32(a, w_cd, b32, out, EPI_GELU if gelu else EPI_BIAS)
+        elif not gelu:
+            ops.gemm_bias(a, w_cd, b32, out)
+        elif ops.gemm_bias_gelu_dual_supported(rows, weight.shape[0], a.shape[1]):
+            pre = torch.empty_like(out)
+            ops.gemm_bias_gelu_dual(a, w_cd, b32, pre, out)
+        else:
+            ops.gemm_bias_gelu(a, w_cd, b32, out)
+        ctx.gelu = gelu
+        ctx.save_for_backward(a, weight, bias, w_cd, w_t, pre)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, weight, bias, w_cd, w_t, pre = ctx.saved_tensors
+        g = _operand(g.contiguous(), a.dtype)
+        if ctx.gelu:
+            if pre is None:                                       # not kept by the forward: recomputed
+                pre = F.linear(a, w_cd, None if bias is None else bias.detach().to(a.dtype))
+            g = torch.ops.aten.gelu_backward(g, pre)
+        ga, gw, gb = _linear_backward(g, a, w_cd, w_t, weight, bias)
+        return ga, gw, gb, None, None, None
+
+
+def _attention_dropout(qkv, scale, p):
+    """models/transformer.py:43-46 with the Dropout on the probabilities active: the probabilities have to exist as
+    a tensor, so this is torch arithmetic (f32 softmax), differentiated by autograd."""
+    _, B, H, N, hd = qkv.shape
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    att = ((q.float() @ k.float().transpose(-2, -1)) * scale).softmax(-1)
+    att = F.dropout(att, p, True)
+    return (att.to(v.dtype) @ v).transpose(1, 2).reshape(B, N, H * hd)
+
+
+def _forward_train_dropout(model, xs, w, cd, B, N, p, p_attn):
+    """The encoder of forward_train with the reference's Dropout layers active (training mode, dropout or
+    attn_dropout > 0): embedding (models/vision_transformer.py:51), attention probabilities (transformer.py:45),
+    attention branch (transformer.py:70), after GELU and after fc2 (transformer.py:23,25).  The masks come from
+    torch's generator (F.dropout), so a seeded run is reproducible; every GEMM, LayerNorm and (without
+    attn_dropout) the attention are the same kernels as elsewhere, as separate graph nodes."""
+    D, H = model.hidden_size, model.num_heads
+    hd = D // H
+    x2 = F.dropout(xs, p, True).view(B * N, D)
+    for i, blk in enumerate(model.encoder.blocks):
+        q = f"b{i}."
+        att, mlp = blk.attention, blk.mlp
+        y, _ = LayerNormFn.apply(x2, blk.norm1.weight, blk.norm1.bias, float(blk.norm1.eps), cd)
+        qkv = QkvFn.apply(y, att.in_proj.weight, att.in_proj.bias, w[q + "qkv.w"], w.get(q + "qkv.wt"), B, N, H, hd)
+        ctxt = _attention_dropout(qkv, att.scaling, p_attn) if p_attn > 0. else AttentionFn.apply(qkv, att.scaling)
+        o = LinearFn.apply(ctxt.reshape(B * N, D), att.out_proj.weight, att.out_proj.bias, w[q + "out.w"], w.get(q + "out.wt"), False)
+        x2 = x2 + F.dropout(o.float(), p, True)
+        y, _ = LayerNormFn.apply(x2, blk.norm2.weight, blk.norm2.bias, float(blk.norm2.eps), cd)
+        h = LinearFn.apply(y, mlp.fc1.weight, mlp.fc1.bias, w[q + "fc1.w"], w.get(q + "fc1.wt"), True)
+        h = F.dropout(h.float(), p, True).to(cd)                 # masks drawn on f32 tensors in both modes: one seed, one mask
+        z = LinearFn.apply(h, mlp.fc2.weight, mlp.fc2.bias, w[q + "fc2.w"], w.get(q + "fc2.wt"), False)
+        x2 = x2 + F.dropout(z.float(), p, True)
+    return x2
+
+
+def _forward_train_fused(model, x2, w, cd, B, N):
+    """The encoder blocks without dropout: each residual branch and the LayerNorm after it as one graph node."""
+    D, H = model.hidden_size, model.num_heads
+    hd = D // H
+    blocks = list(model.encoder.blocks)
+    if blocks:
+        n1 = blocks[0].norm1
+        y, x2 = LayerNormFn.apply(x2, n1.weight, n1.bias, float(n1.eps), cd)
+    for i, blk in enumerate(blocks):
+        p = f"b{i}."
+        att, mlp = blk.attention, blk.mlp
+        qkv = QkvFn.apply(y, att.in_proj.weight, att.in_proj.bias, w[p + "qkv.w"], w.get(p + "qkv.wt"), B, N, H, hd)
+        ctxt = AttentionFn.apply(qkv, att.scaling)
+        y, x2 = ResidualBranchFn.apply(ctxt.view(B * N, D), x2, att.out_proj.weight, att.out_proj.bias, w[p + "out.w"],
+                                       w.get(p + "out.wt"), None, None, None, None,
+                                       blk.norm2.weight, blk.norm2.bias, float(blk.norm2.eps))
+        nxt = blocks[i + 1].norm1 if i + 1 < len(blocks) else None        # the next block's first LayerNorm
+        res = ResidualBranchFn.apply(y, x2, mlp.fc2.weight, mlp.fc2.bias, w[p + "fc2.w"], w.get(p + "fc2.wt"),
+                                     mlp.fc1.weight, mlp.fc1.bias, w[p + "fc1.w"], w.get(p + "fc1.wt"),
+                                     None if nxt is None else nxt.weight, None if nxt is None else nxt.bias,
+                                     0.0 if nxt is None else float(nxt.eps))
+        if nxt is None:
+            x2 = res
+        else:
+            y, x2 = res
+    return x2
+
+
 def forward_train(model, x):
     """The forward of vit_amd.VisionTransformer with autograd: same kernels, fresh tensors per op."""
     w = model._cache.get(train=True)
@@ -366,28 +465,12 @@ def forward_train(model, x):
         cols = torch.empty(B * (N - 1), w["embed.w"].shape[1], dtype=torch.bfloat16, device=x.device)
     xs = PatchEmbedFn.apply(img, model.embedding.weight, model.embedding.bias, model.cls_token, model.pos_embed,
                             w["embed.w"], w["embed.b"], w["cls"], w["pos"], P, cols)
-    x2 = xs.view(B * N, D)
-    blocks = list(model.encoder.blocks)
-    if blocks:
-        n1 = blocks[0].norm1
-        y, x2 = LayerNormFn.apply(x2, n1.weight, n1.bias, float(n1.eps), cd)
-    for i, blk in enumerate(blocks):
-        p = f"b{i}."
-        att, mlp = blk.attention, blk.mlp
-        qkv = QkvFn.apply(y, att.in_proj.weight, att.in_proj.bias, w[p + "qkv.w"], w.get(p + "qkv.wt"), B, N, H, hd)
-        ctxt = AttentionFn.apply(qkv, att.scaling)
-        y, x2 = ResidualBranchFn.apply(ctxt.view(B * N, D), x2, att.out_proj.weight, att.out_proj.bias, w[p + "out.w"],
-                                       w.get(p + "out.wt"), None, None, None, None,
-                                       blk.norm2.weight, blk.norm2.bias, float(blk.norm2.eps))
-        nxt = blocks[i + 1].norm1 if i + 1 < len(blocks) else None        # the next block's first LayerNorm
-        res = ResidualBranchFn.apply(y, x2, mlp.fc2.weight, mlp.fc2.bias, w[p + "fc2.w"], w.get(p + "fc2.wt"),
-                                     mlp.fc1.weight, mlp.fc1.bias, w[p + "fc1.w"], w.get(p + "fc1.wt"),
-                                     None if nxt is None else nxt.weight, None if nxt is None else nxt.bias,
-                                     0.0 if nxt is None else float(nxt.eps))
-        if nxt is None:
-            x2 = res
-        else:
-            y, x2 = res
+    p = float(model.dropout.p) if model.training else 0.
+    p_attn = float(model.encoder.blocks[0].attention.dropout.p) if model.training and len(model.encoder.blocks) else 0.
+    if p > 0. or p_attn > 0.:
+        x2 = _forward_train_dropout(model, xs, w, cd, B, N, p, p_attn)
+    else:
+        x2 = _forward_train_fused(model, xs.view(B * N, D), w, cd, B, N)
     cls_rows = x2.view(B, N, D)[:, 0].contiguous()                         # the reference keeps token 0 (transformer.py:99)
     norm = model.encoder.norm
     feat, _ = LayerNormFn.apply(cls_rows, norm.weight, norm.bias, float(norm.eps), torch.float32)

@@ -108,8 +108,6 @@ class VisionTransformer(nn.Module):
     def _forward(self, x):
         if x.dim() != 4 or x.shape[1] != 3:
             raise VitkError(f"expected images [B,3,H,W], got {tuple(x.shape)}")
-        if self.training and self._p_dropout > 0.:
-            raise VitkError("dropout > 0 in training mode is not implemented on this path")
         w = self._cache.get()
         if w["pos"].device != x.device:
             raise VitkError(f"model is on {w['pos'].device}, input on {x.device}")
@@ -118,8 +116,10 @@ class VisionTransformer(nn.Module):
         N = (Hi // P) * (Wi // P) + 1
         if N != w["pos"].shape[0]:
             raise VitkError(f"input {Hi}x{Wi} gives {N} tokens but pos_embed holds {w['pos'].shape[0]}")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            # training (main.py:207-223): the same kernels as autograd Functions, fresh tensors per op
+        if (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())) or \
+                (self.training and self._p_dropout > 0.):
+            # training (main.py:207-223): the same kernels as autograd Functions, fresh tensors per op; active
+            # Dropout layers (training mode, dropout or attn_dropout > 0) exist on that path only
             return forward_train(self, x)
         ws = self._workspace(x.device, B, N)
         out_dtype = self.head.weight.dtype

@@ -2,14 +2,14 @@
 
 The reference trains the same module it evaluates (main.py:207-223: `loss = criterion(model(images),
 target); loss.backward(); clip_grad_norm_; optimizer.step()`).  Here every forward op is still a libvitk
-kernel; each Function keeps what its backward needs and computes the gradients with torch operations on
-the GPU (library GEMMs, aten backward ops), recomputing cheap intermediates instead of storing them.
+kernel; each Function keeps what its backward needs, recomputing cheap intermediates instead of storing them.
 Gradients arrive at the module's ordinary fp32 Parameters, so optimizers, `clip_grad_norm_` and
 DistributedDataParallel work unchanged.  In the bf16 mode every gradient of the blocks comes from a libvitk
-kernel: LayerNorm backward, the weight-gradient GEMM (dW = dY^T X), bias column sums, attention backward, and
-the input gradients dX = dY W through the forward GEMM kernel on the transposed weight, with GELU' / tanh' in
-its epilogue.  torch operations remain for the fp32 mode, for shapes the kernels do not take (rows that do not
-fill 64-row tiles, head sizes other than 64) and for casts, slices and small reductions.
+kernel: LayerNorm backward, the weight-gradient GEMM (dW = dY^T X, which also sums dY's columns for the bias),
+attention backward, and the input gradients dX = dY W through the forward GEMM kernel on the transposed weight,
+with GELU' / tanh' in its epilogue.  torch operations remain for the fp32 mode's backward, for shapes the kernels
+do not take (rows that do not fill 64-row tiles, head sizes other than 64), for casts, slices and small
+reductions, and for the masks (and, with attn_dropout > 0, the attention) of the training path with dropout.
 
 cd = compute dtype of the GEMM operands: torch.bfloat16, or torch.float32 in the fp32 mode.
 """

@@ -238,6 +238,36 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
 #pragma unroll
                 for (int i = 0; i < 16; ++i) o_acc[d][i] *= alpha;
         }
+        // OVL: V^T fragments of the first 16-key slice are requested before the exponentials (the inline asm is a
+        // scheduling barrier: issued after them, the first P.V of every step would wait out the LDS latency)
+        constexpr int G = NB * 2;
+        bf16x4 vv[2][DB][2];
+        auto issue = [&](int g, bf16x4 (&dst)[DB][2]) {
+            const int u = g >> 1, st = g & 1;
+            const int ka = (lb + u) * 32 + 16 * st + 4 * hh + tq;
+#pragma unroll
+            for (int d = 0; d < DB; ++d) {
+                const int chunk = d * 4 + tsub * 2 + (tp >> 1);
+                const char* a0 = v_lds + ka * RB + ((chunk ^ v_swz(ka)) << 4) + (tp & 1) * 8;
+                const uint32_t addr = (uint32_t)(uintptr_t)(lds_void*)a0;
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst[d][0]) : "v"(addr));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst[d][1]) : "v"(addr), "n"(8 * RB));
+            }
+        };
+        auto landed = [&](bf16x4 (&w)[DB][2], auto last_c) {
+            constexpr bool last = decltype(last_c)::value;       // no younger group in flight
+            if constexpr (DB == 2) {
+                if constexpr (last) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]));
+                else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]));
+            } else {
+                if constexpr (last) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[2][0]), "+v"(w[2][1]));
+                else asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[2][0]), "+v"(w[2][1]));
+            }
+        };
+        if constexpr (OVL) {
+            issue(0, vv[0]);
+            issue(1, vv[1]);
+        }
         float psum = 0.f;
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
@@ -254,48 +284,24 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
             // the builtin, the compiler puts an s_waitcnt vmcnt(0) in front of them for as long as any
             // LDS-DMA is in flight (it cannot tell that the DMA fills the other buffer), i.e. the first
             // P.V of a head would wait for the whole staging of the next head.  Groups of 2 DB reads
-            // (one 16-key slice) are issued one group ahead of the MFMAs that use them; the wait is tied to
-            // the group's registers so that the MFMAs cannot move above it.
-            constexpr int G = NB * 2;
-            bf16x4 vv[2][DB][2];
-            auto issue = [&](int g, bf16x4 (&dst)[DB][2]) {
-                const int u = g >> 1, st = g & 1;
-                const int ka = (lb + u) * 32 + 16 * st + 4 * hh + tq;
-#pragma unroll
-                for (int d = 0; d < DB; ++d) {
-                    const int chunk = d * 4 + tsub * 2 + (tp >> 1);
-                    const char* a0 = v_lds + ka * RB + ((chunk ^ v_swz(ka)) << 4) + (tp & 1) * 8;
-                    const uint32_t addr = (uint32_t)(uintptr_t)(lds_void*)a0;
-                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst[d][0]) : "v"(addr));
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst[d][1]) : "v"(addr), "n"(8 * RB));
-                }
-            };
-            auto landed = [&](bf16x4 (&w)[DB][2], auto last_c) {
-                constexpr bool last = decltype(last_c)::value;       // no younger group in flight
-                if constexpr (DB == 2) {
-                    if constexpr (last) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]));
-                    else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]));
-                } else {
-                    if constexpr (last) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[2][0]), "+v"(w[2][1]));
-                    else asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[2][0]), "+v"(w[2][1]));
-                }
-            };
-            issue(0, vv[0]);
+            // (one 16-key slice) are issued two groups ahead of the MFMAs that use them (the first two before the
+            // exponentials); the wait is tied to the group's registers so that the MFMAs cannot move above it.
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const int u = g >> 1, st = g & 1;
-                if (g + 1 < G) issue(g + 1, vv[(g + 1) & 1]);
                 u32x4 pk = {pack_bf16(s[u][8 * st + 0], s[u][8 * st + 1]), pack_bf16(s[u][8 * st + 2], s[u][8 * st + 3]),
                             pack_bf16(s[u][8 * st + 4], s[u][8 * st + 5]), pack_bf16(s[u][8 * st + 6], s[u][8 * st + 7])};
                 const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
                 if (g + 1 < G) landed(vv[g & 1], std::false_type{});
                 else landed(vv[g & 1], std::true_type{});
+                // copies: the slot is refilled (slice g + 2) while these MFMAs are still being issued
+                bf16x8 vf[DB];
 #pragma unroll
-                for (int d = 0; d < DB; ++d) {
-                    const bf16x8 vf = __builtin_shufflevector(vv[g & 1][d][0], vv[g & 1][d][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                    o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o_acc[d], 0, 0, 0);
-                }
+                for (int d = 0; d < DB; ++d) vf[d] = __builtin_shufflevector(vv[g & 1][d][0], vv[g & 1][d][1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int d = 0; d < DB; ++d) o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[d], pf, o_acc[d], 0, 0, 0);
                 l_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, l_acc, 0, 0, 0);
+                if (g + 2 < G) issue(g + 2, vv[g & 1]);
             }
         } else {
 #pragma unroll

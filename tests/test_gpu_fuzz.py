@@ -1,0 +1,144 @@
+"""Seeded random shapes through the C ABI: the hand-picked shapes of test_gpu_kernels.py are the models' own; these
+sweep what lies between them (tile edges, ragged rows, odd token counts, every kernel-selection boundary) against
+plain torch arithmetic on the same bf16-rounded operands (fp32 / fp64 on the GPU).  Tolerances as in
+test_gpu_kernels.py: fp32 summation order and one bf16 rounding on store."""
+import random
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from vit_amd import lib, ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _gemm_shapes(n, seed):
+    rng = random.Random(seed)
+    out = []
+    for _ in range(n):
+        kind = rng.random()
+        if kind < 0.6:          # tiled kernels: N multiple of 256, K of 64, any M >= 128
+            M = rng.choice([128, 129, 255, 256, 257, 300, 511, 1000, 1576, 2047, 3000, 4099, 6500])
+            N = 256 * rng.randint(1, 6)
+            K = 64 * rng.randint(1, 24)
+        else:                   # small kernel: anything with K % 32 == 0
+            M = rng.randint(1, 200)
+            N = rng.choice([8, 10, 64, 100, 250, 256, 1000, 1001])
+            K = 32 * rng.randint(1, 40)
+        out.append((M, N, K))
+    return out
+
+
+def _operands(M, N, K, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    a = torch.randn(M, K, generator=g, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g, device=DEV) * 0.05).to(torch.bfloat16)
+    b = torch.randn(N, generator=g, device=DEV) * 0.1
+    return a, w, b
+
+
+@pytest.mark.parametrize("M,N,K", _gemm_shapes(36, 1))
+def test_fuzz_gemm_epilogues(M, N, K):
+    a, w, b = _operands(M, N, K, M * 7 + N + K)
+    acc = a.float() @ w.float().t() + b
+    atol32 = 2e-4 * max(K / 768, 1.0) ** 0.5
+    out32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm_bias(a, w, b, out32)
+    assert torch.allclose(out32, acc, rtol=1e-4, atol=atol32)
+    out16 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_bias(a, w, None, out16)
+    assert torch.allclose(out16.float(), acc - b, rtol=2 ** -7, atol=2e-3)
+    ops.gemm_bias_gelu(a, w, b, out16)
+    assert torch.allclose(out16.float(), F.gelu(acc), rtol=2 ** -7, atol=2e-3)
+    ops.gemm_bias_tanh(a, w, b, out16)
+    assert torch.allclose(out16.float(), torch.tanh(acc), rtol=2 ** -7, atol=2e-3)
+    resid = torch.randn(M, N, device=DEV)
+    x = resid.clone()
+    ops.gemm_bias_residual(a, w, b, x, x)
+    assert torch.allclose(x, resid + acc, rtol=1e-4, atol=atol32)
+    if ops.gemm_bias_gelu_dual_supported(M, N, K):
+        pre = torch.empty_like(out16)
+        ops.gemm_bias_gelu_dual(a, w, b, pre, out16)
+        assert torch.allclose(pre.float(), acc, rtol=2 ** -7, atol=2e-3)
+        assert torch.allclose(out16.float(), F.gelu(acc), rtol=2 ** -7, atol=2e-3)
+    aux = torch.randn(M, N, device=DEV).to(torch.bfloat16)
+    ops.gemm_grad_act(a, w, aux, out16, lib.ACT_TANH)
+    want = (acc - b).to(torch.bfloat16).float() * (1 - aux.float() ** 2)
+    assert torch.allclose(out16.float(), want, rtol=2 ** -6, atol=4e-3)
+
+
+def _attn_cases(n, seed):
+    rng = random.Random(seed)
+    out = []
+    for _ in range(n):
+        hd = rng.choice([64, 64, 64, 80, 96])
+        N = rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 100, 160, 161, 196, 197, 255, 256, 257, 288, 289, 320, 400, 576, 577,
+                        608, 609, 700, 1000])
+        B, H = rng.randint(1, 3), rng.randint(1, 5)
+        if N > 600:
+            B, H = 1, rng.randint(1, 2)
+        out.append((B, H, N, hd))
+    return out
+
+
+@pytest.mark.parametrize("B,H,N,hd", _attn_cases(40, 2))
+def test_fuzz_attention(B, H, N, hd):
+    g = torch.Generator(device=DEV).manual_seed(B * 100000 + H * 10000 + N * 10 + hd)
+    qkv = torch.randn(3, B, H, N, hd, generator=g, device=DEV).to(torch.bfloat16)
+    scale = hd ** -0.5
+    q, k, v = (qkv[i].double() for i in range(3))
+    want = (((q @ k.transpose(-2, -1)) * scale).softmax(-1) @ v).transpose(1, 2).reshape(B, N, H * hd)
+    out = torch.empty(B, N, H * hd, dtype=torch.bfloat16, device=DEV)
+    ops.attention(qkv, out, scale)
+    assert torch.allclose(out.double(), want, rtol=2e-2, atol=6e-3), float((out.double() - want).abs().max())
+    if hd == 64 and ops.attention_backward_supported(N, hd):
+        dctx = torch.randn(B, N, H * hd, generator=g, device=DEV).to(torch.bfloat16)
+        qd, kd, vd = (qkv[i].double().requires_grad_(True) for i in range(3))
+        o = (((qd @ kd.transpose(-2, -1)) * scale).softmax(-1) @ vd).transpose(1, 2).reshape(B, N, H * hd)
+        gq, gk, gv = torch.autograd.grad(o, (qd, kd, vd), dctx.double())
+        wantg = torch.stack((gq, gk, gv)).permute(1, 3, 0, 2, 4)
+        lse = ops.attention_lse(qkv, out, scale)
+        got = ops.attention_backward(qkv, out, dctx, lse, scale)
+        err = (got.double() - wantg).abs().max().item()
+        assert err <= 3e-2 * max(1.0, wantg.abs().max().item()), f"attention backward: {err:.3e}"
+
+
+def _tn_shapes(n, seed):
+    rng = random.Random(seed)
+    return [(64 * rng.randint(1, 200), 256 * rng.randint(1, 5), 256 * rng.randint(1, 5)) for _ in range(n)]
+
+
+@pytest.mark.parametrize("R,M,N", _tn_shapes(10, 3))
+def test_fuzz_weight_gradient_gemm_with_column_sums(R, M, N):
+    g = torch.Generator(device=DEV).manual_seed(R + M + N)
+    gd = (torch.randn(R, M, generator=g, device=DEV) * 0.5).to(torch.bfloat16)
+    xd = torch.randn(R, N, generator=g, device=DEV).to(torch.bfloat16)
+    cs = torch.full((M,), float("nan"), device=DEV)
+    got = ops.gemm_tn(gd, xd, colsum=cs)
+    tol = 1e-5 * (R ** 0.5) * 4 + 1e-6
+    assert (got.double() - gd.double().t() @ xd.double()).abs().max().item() <= tol
+    assert (cs.double() - gd.double().sum(0)).abs().max().item() <= tol
+    assert torch.equal(got, ops.gemm_tn(gd, xd))
+
+
+@pytest.mark.parametrize("rows,D", [(1, 256), (3, 512), (17, 768), (197, 1024), (1000, 1280), (4097, 768)])
+def test_fuzz_layernorm_forward_and_backward(rows, D):
+    g = torch.Generator(device=DEV).manual_seed(rows * D)
+    x = torch.randn(rows, D, generator=g, device=DEV) * 2 + 0.3
+    gamma = 1 + 0.1 * torch.randn(D, generator=g, device=DEV)
+    beta = 0.1 * torch.randn(D, generator=g, device=DEV)
+    out = torch.empty(rows, D, dtype=torch.bfloat16, device=DEV)
+    ops.layernorm(x, gamma, beta, 1e-6, out)
+    assert torch.allclose(out.float(), F.layer_norm(x, (D,), gamma, beta, 1e-6), rtol=2 ** -8, atol=1e-5)
+    gy = torch.randn(rows, D, generator=g, device=DEV)
+    xd = x.double().requires_grad_(True)
+    gd = gamma.double().requires_grad_(True)
+    bd = beta.double().requires_grad_(True)
+    y = F.layer_norm(xd, (D,), gd, bd, 1e-6)
+    wx, wg, wb = torch.autograd.grad(y, (xd, gd, bd), gy.double())
+    dx, dgamma, dbeta = ops.layernorm_backward(x, gamma, gy, 1e-6)
+    assert torch.allclose(dx.double(), wx, rtol=1e-4, atol=2e-5)
+    assert torch.allclose(dgamma.double(), wg, rtol=1e-4, atol=1e-4 * rows ** 0.5)
+    assert torch.allclose(dbeta.double(), wb, rtol=1e-4, atol=1e-4 * rows ** 0.5)

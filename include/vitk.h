@@ -70,7 +70,7 @@ void vitk_set_debug_variant(int gemm_variant, int attention_variant);
 int vitk_layernorm(const float* x, int64_t x_row_stride, const float* gamma, const float* beta, void* y,
                    int64_t y_row_stride, int rows, int D, float eps, int out_dtype, void* stream);
 
-/* out[i] = bf16(in[i]), n % 8 == 0.  Input images arrive fp32 when the caller has not cast them. */
+/* out[i] = bf16(in[i]), any n > 0.  Input images arrive fp32 when the caller has not cast them. */
 int vitk_cast_f32_bf16(const float* in, void* out, int64_t n, void* stream);
 
 /* Patch embedding + cls token + position embedding:
@@ -86,7 +86,8 @@ int vitk_patch_embed(const void* img, const void* w, const float* bias, const fl
 /* The same result for any patch size (ViT-H/14's 14 included), through an explicit patch matrix:
  * cols: caller-provided scratch, bf16 [batch * (img_h/patch) * (img_w/patch), Kpad] with
  * Kpad = 3*patch*patch rounded up to a multiple of 64; w_padded: bf16 [D, Kpad], the flattened Conv2d
- * weight zero-padded to Kpad columns.  At least 128 patch rows, D % 256 == 0.
+ * weight zero-padded to Kpad columns.  D % 256 == 0; any image size (also the route for a width that is not a
+ * multiple of 8).
  * models/vision_transformer.py:47-50. */
 int vitk_patch_embed_cols(const void* img, const void* w_padded, const float* bias, const float* cls,
                           const float* pos, float* x, void* cols, int batch, int img_h, int img_w, int patch, int D,

@@ -461,7 +461,7 @@ def forward_train(model, x):
     else:
         raise VitkError(f"unsupported image dtype {x.dtype}")
     cols = None
-    if not fp32 and w["embed.w"].shape[1] != 3 * P * P:                    # explicit patch matrix (non-power-of-two patch)
+    if not fp32 and (w["embed.w"].shape[1] != 3 * P * P or Wi % 8 != 0):   # explicit patch matrix (patch not a power of two, or odd width)
         cols = torch.empty(B * (N - 1), w["embed.w"].shape[1], dtype=torch.bfloat16, device=x.device)
     xs = PatchEmbedFn.apply(img, model.embedding.weight, model.embedding.bias, model.cls_token, model.pos_embed,
                             w["embed.w"], w["embed.b"], w["cls"], w["pos"], P, cols)

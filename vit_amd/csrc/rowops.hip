@@ -111,7 +111,7 @@ hipError_t launch_cls_pos(const float* cls, const float* pos, float* x, int batc
 
 // fp32 -> bf16, 8 elements (32 B in, 16 B out) per lane per step; n % 8 == 0.
 __global__ __launch_bounds__(256) void cast_f32_bf16(const float* __restrict__ in, bf16_t* __restrict__ out,
-                                                     int64_t n8) {
+                                                     int64_t n8, int tail) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(in + i * 8);
@@ -119,6 +119,8 @@ __global__ __launch_bounds__(256) void cast_f32_bf16(const float* __restrict__ i
         u32x4 o = {pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3]), pack_bf16(b[0], b[1]), pack_bf16(b[2], b[3])};
         *reinterpret_cast<u32x4*>(out + i * 8) = o;
     }
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail)             // the last n % 8 elements
+        out[n8 * 8 + threadIdx.x] = (bf16_t)in[n8 * 8 + threadIdx.x];
 }
 
 hipError_t launch_cast_f32_bf16(const float* in, void* out, int64_t n, hipStream_t s) {
@@ -127,7 +129,7 @@ hipError_t launch_cast_f32_bf16(const float* in, void* out, int64_t n, hipStream
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(cast_f32_bf16, dim3((unsigned)blocks), dim3(256), 0, s, in,
-                       reinterpret_cast<bf16_t*>(out), n8);
+                       reinterpret_cast<bf16_t*>(out), n8, (int)(n - n8 * 8));
     return hipGetLastError();
 }
 
@@ -224,8 +226,34 @@ __global__ __launch_bounds__(256) void normalize_u8(const uint8_t* __restrict__ 
     }
 }
 
+// the same per pixel, for planes whose size is not a multiple of 16 (a 16-pixel group would straddle channels)
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void normalize_u8_any(const uint8_t* __restrict__ in, void* __restrict__ out, int64_t n,
+                                                        int64_t plane, float m0, float m1, float m2, float s0, float s1,
+                                                        float s2) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int c = (int)((i / plane) % 3);
+        const float m = c == 0 ? m0 : c == 1 ? m1 : m2, sd = c == 0 ? s0 : c == 1 ? s1 : s2;
+        const float v = ((float)in[i] - m) / sd;
+        if constexpr (OUT_BF16) reinterpret_cast<bf16_t*>(out)[i] = (bf16_t)v;
+        else reinterpret_cast<float*>(out)[i] = v;
+    }
+}
+
 hipError_t launch_normalize_u8(const void* in, void* out, int64_t n, int64_t plane, const float* mean,
                                const float* std, bool out_bf16, hipStream_t s) {
+    if (plane % 16 != 0) {
+        int64_t blocks = (n + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        if (out_bf16)
+            hipLaunchKernelGGL(normalize_u8_any<true>, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const uint8_t*>(in),
+                               out, n, plane, mean[0], mean[1], mean[2], std[0], std[1], std[2]);
+        else
+            hipLaunchKernelGGL(normalize_u8_any<false>, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const uint8_t*>(in),
+                               out, n, plane, mean[0], mean[1], mean[2], std[0], std[1], std[2]);
+        return hipGetLastError();
+    }
     const int64_t n16 = n / 16;
     int64_t blocks = (n16 + 255) / 256;
     if (blocks > 4096) blocks = 4096;

@@ -88,7 +88,7 @@ int vitk_layernorm(const float* x, int64_t x_row_stride, const float* gamma, con
 
 int vitk_cast_f32_bf16(const float* in, void* out, int64_t n, void* stream) {
     if (!in || !out) return fail(VITK_ERR_INVALID, "vitk_cast_f32_bf16: null pointer");
-    if (n <= 0 || n % 8 != 0) return fail(VITK_ERR_INVALID, "vitk_cast_f32_bf16: n=%lld must be a positive multiple of 8", (long long)n);
+    if (n <= 0) return fail(VITK_ERR_INVALID, "vitk_cast_f32_bf16: n=%lld must be positive", (long long)n);
     if (!aligned16(in) || !aligned16(out)) return fail(VITK_ERR_INVALID, "vitk_cast_f32_bf16: misaligned pointer");
     return launched(launch_cast_f32_bf16(in, out, n, reinterpret_cast<hipStream_t>(stream)), "vitk_cast_f32_bf16");
 }
@@ -133,8 +133,6 @@ int vitk_patch_embed_cols(const void* img, const void* w_padded, const float* bi
     const int gh = img_h / patch, gw = img_w / patch;   // Conv2d without padding floors
     if (gh < 1 || gw < 1) return fail(VITK_ERR_INVALID, "vitk_patch_embed_cols: image smaller than one patch");
     const int kpad = (3 * patch * patch + 63) / 64 * 64;
-    if ((size_t)batch * gh * gw < 128)
-        return fail(VITK_ERR_UNSUPPORTED, "vitk_patch_embed_cols: fewer than 128 patch rows");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rc = launched(launch_im2col(img, cols, batch, img_h, img_w, patch, kpad, s), "vitk_patch_embed_cols(im2col)");
     if (rc) return rc;
@@ -302,7 +300,6 @@ int vitk_normalize_u8(const void* img, void* out, int batch, int img_h, int img_
         return fail(VITK_ERR_UNSUPPORTED, "vitk_normalize_u8: out_dtype=%d", out_dtype);
     if (!aligned16(img) || !aligned16(out)) return fail(VITK_ERR_INVALID, "vitk_normalize_u8: pointers must be 16-byte aligned");
     const int64_t plane = (int64_t)img_h * img_w;
-    if (plane % 16 != 0) return fail(VITK_ERR_UNSUPPORTED, "vitk_normalize_u8: img_h*img_w=%lld not a multiple of 16", (long long)plane);
     for (int c = 0; c < 3; ++c)
         if (!(std[c] > 0.f)) return fail(VITK_ERR_INVALID, "vitk_normalize_u8: std[%d] must be positive", c);
     return launched(launch_normalize_u8(img, out, (int64_t)batch * 3 * plane, plane, mean, std, out_dtype == VITK_BF16,

@@ -26,9 +26,10 @@ def _bf16(t):
     return t.detach().to(torch.bfloat16).contiguous()
 
 
-def gather_patch_ok(patch):
-    """Patch sizes the GEMM's im2col-free gather loader addresses: powers of two >= 8."""
-    return patch >= 8 and (patch & (patch - 1)) == 0
+def gather_patch_ok(patch, img_w=0):
+    """What the GEMM's im2col-free gather loader addresses: patch sizes that are powers of two >= 8, in images
+    whose width is a multiple of 8 (16-byte runs of a row).  Everything else goes through the patch matrix."""
+    return patch >= 8 and (patch & (patch - 1)) == 0 and img_w % 8 == 0
 
 
 class WeightCache:

@@ -148,7 +148,7 @@ class VisionTransformer(nn.Module):
         else:
             raise VitkError(f"unsupported image dtype {x.dtype}")
 
-        if gather_patch_ok(P):
+        if gather_patch_ok(P, Wi):
             ops.patch_embed(img16, w["embed.w"], w["embed.b"], w["cls"], w["pos"], ws.x, P)
         else:
             cols = ws.patch_cols(B * (N - 1), w["embed.w"].shape[1], x.device)

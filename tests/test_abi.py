@@ -43,7 +43,7 @@ def test_argument_errors_are_reported_not_launched():
     assert L.vitk_gemm_bias_residual(p, p, p, None, p, 16, 16, 64, None) == 1
     assert L.vitk_patch_embed(p, p, p, p, p, p, 1, 224, 224, 14, 1280, None) == 2  # patch 14
     assert L.vitk_qkv_proj(p, p, p, p, 1, 197, 12, 60, None) == 2
-    assert L.vitk_cast_f32_bf16(p, p, 12, None) == 1
+    assert L.vitk_cast_f32_bf16(p, p, 0, None) == 1
     assert L.vitk_gemm_f32(p, p, p, None, p, 16, 16, 64, 2, None) == 1             # residual epilogue without residual
     assert L.vitk_gemm_f32(p, p, p, None, p, 16, 16, 64, 9, None) == 1             # epilogue code
     assert L.vitk_attention_f32(p, p, p, p, 1, 1, 197, 48, 0.1, None) == 2         # head_dim

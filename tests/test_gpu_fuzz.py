@@ -198,3 +198,35 @@ def test_fuzz_whole_model_against_the_oracle(case):
     # bf16 mode: the 1e-2 bar belongs to the reference's configurations (tests/test_gpu_model.py); perturbed weights
     # at D = 1280 reach 1.1e-2, an indexing mistake anywhere gives 1e-1 and more
     assert (got - want).abs().max().item() <= 2e-2
+
+
+@pytest.mark.parametrize("g,G,D", [(2, 3, 8), (14, 24, 768), (24, 14, 768), (7, 7, 64), (3, 37, 100), (16, 5, 257), (1, 4, 16), (12, 13, 1280)])
+def test_fuzz_pos_embed_scale(g, G, D):
+    import numpy as np
+
+    import vit_amd
+    from oracle import pos_embed_oracle as po
+    rng = np.random.default_rng(g * 100 + G)
+    pos = rng.standard_normal((1, 1 + g * g, D)).astype(np.float32)
+    patch = 4
+    want = po.pos_embed_scale(pos, G * patch, patch)
+    got = vit_amd.pos_embed_scale(torch.from_numpy(pos).to(DEV), G * patch, patch)
+    assert tuple(got.shape) == want.shape
+    assert np.abs(got.cpu().numpy() - want).max() <= 5e-6
+
+
+@pytest.mark.parametrize("rows,classes", [(1, 2), (7, 10), (64, 1000), (257, 1000), (33, 21843), (5, 3)])
+def test_fuzz_accuracy(rows, classes):
+    import numpy as np
+
+    import vit_amd
+    from oracle import io_oracle as io
+    rng = np.random.default_rng(rows + classes)
+    out = rng.standard_normal((rows, classes)).astype(np.float32)
+    out[rows // 2, :] = out[rows // 2, 0]                     # a row of ties: the lower index wins
+    tgt = rng.integers(0, classes, rows)
+    ks = tuple(k for k in (1, 5) if k <= classes)
+    got = vit_amd.accuracy(torch.from_numpy(out).to(DEV), torch.from_numpy(tgt).to(DEV), topk=ks)
+    want = io.accuracy(out, tgt, topk=ks)
+    for a, b in zip(got, want):
+        assert abs(float(a) - float(b)) <= 1e-4

@@ -47,7 +47,8 @@ const char* vitk_last_error(void);
  *   plain matrix, else the one-group pipelined kernel), 1 = basic kernel with LDS-DMA staging, 2 = force
  *   the small untiled kernel, 3 = basic kernel with register staging, 5 = one-group pipelined kernel.
  *   gemm_variant >> 4 (= "order"): bits 0-3 tile order (1 = no n-grouping, 3 = group width from bits
- *   4-7), bits 8-12 force the tile height (in 16-row units).
+ *   4-7), bits 8-12 force the tile height (in 16-row units), bit 13 = equal tiles where the two-height plan
+ *   would apply.
  *   Timing probes (WRONG OR NO RESULTS) exist only in diagnostic builds of the library (-DVITK_PROBES,
  *   `python -m vit_amd.build --probes` -> libvitk_probes.so), never in libvitk.so: order bits 17-19 on the
  *   bias -> bf16 epilogue of the default kernel (1 = no DMA, 2 = no epilogue, 3 = accumulator clearing

@@ -266,3 +266,29 @@ def test_unsupported_head_dim_raises():
     ctx = torch.empty(1, 197, 384, dtype=torch.bfloat16, device=DEV)
     with pytest.raises(lib.VitkError, match="hd=48"):
         ops.attention(qkv, ctx, 0.1)
+
+
+# ----------------------------------------------------------------------------- full-size launches
+@pytest.mark.parametrize("M,N,K", [(50432, 768, 768), (50432 + 77, 768, 768), (50432, 1024, 1024), (73856, 768, 768),
+                                   (50432, 768, 3072), (40000, 512, 256)])
+def test_gemm_tile_plans_at_full_size(M, N, K):
+    """Shapes with at least one output tile per CU and few n-tiles take the two-height tile plan (an XCD's rows cut
+    into tall panels, then shorter ones): every element against a torch product on the GPU, and bit-identical to the
+    equal-tile plan (debug order bit 13), which accumulates each element in the same order."""
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g, device=DEV) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g, device=DEV) * 0.1
+    resid = torch.randn(M, N, generator=g, device=DEV)
+    outs = []
+    for variant in (0, 0x20000):
+        lib.load().vitk_set_debug_variant(variant, 0)
+        x = resid.clone()
+        ops.gemm_bias_residual(a, w, bias, x, x)
+        o16 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        ops.gemm_bias_gelu(a, w, bias, o16)
+        outs.append((x, o16))
+    acc = a.float() @ w.float().t() + bias
+    assert torch.allclose(outs[0][0], resid + acc, rtol=1e-4, atol=2e-4 * max(K / 768, 1.0) ** 0.5)
+    assert torch.allclose(outs[0][1].float(), F.gelu(acc), rtol=2 ** -7, atol=2e-3)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

@@ -11,7 +11,21 @@ struct PipePlan {
     int tiles_m;     // ceil(M / (16 mtot))
     int tiles_n;     // N / 256
     int gn;          // n-group width of the tile order (0 = plain n-fastest)
+    // Two-height plan (mixed != 0; plain order only): every XCD owns xcd_units * 16 consecutive rows, cut into na
+    // panels of ha m-tiles followed by nb panels of hb m-tiles (tiles_n output tiles per panel).  Its workgroups
+    // take the XCD's tiles round-robin, so each gets tall tiles first and short ones last and the round count need
+    // not be a whole number of equal tiles: 3 tiles of 13 become 13 + 13 + 11 where 2.85 rounds of 13 were needed.
+    int mixed, xcd_units, ha, na, hb, nb;
 };
+
+// tile `local` of XCD `xcd` in the two-height plan -> first row, height (m-tiles), n-tile
+__device__ __forceinline__ void mixed_tile(const PipePlan& pl, int xcd, int local, int& m0, int& mtot, int& tile_n) {
+    const int panel = local / pl.tiles_n;
+    tile_n = local - panel * pl.tiles_n;
+    const bool tall = panel < pl.na;
+    mtot = tall ? pl.ha : pl.hb;
+    m0 = (xcd * pl.xcd_units + (tall ? panel * pl.ha : pl.na * pl.ha + (panel - pl.na) * pl.hb)) * 16;
+}
 
 // position `idx` of the tile order -> (tile_m, tile_n).  Plain: ids walk the n tiles of one
 // activation panel.  Grouped: n tiles in groups of gn; ids walk n inside the group, then m, then
@@ -30,9 +44,33 @@ __device__ __forceinline__ void tile_coords(const PipePlan& pl, int idx, int& ti
     }
 }
 
+// Two-height plan for `units` m-tiles per XCD, tiles_n n-tiles and `slots` workgroups per XCD: the (ha, na, hb) whose
+// busiest workgroup has the fewest m-tiles (workgroup s takes local tiles s, s + slots, ...); hmin <= hb <= ha <= 16.
+// Returns that maximum.
+inline int plan_two_heights(int units, int tiles_n, int slots, int hmin, int& ha, int& na, int& hb, int& nb) {
+    int best = 1 << 30;
+    for (int a = 16; a >= hmin; --a)
+        for (int b = a; b >= hmin; --b)
+            for (int n1 = 0; n1 * a <= units + a - 1; ++n1) {
+                const int rest = units - n1 * a;
+                const int n2 = rest > 0 ? (rest + b - 1) / b : 0;
+                if (a == b && n1 > 0) continue;                      // the uniform plans: once, as (a, 0, a, n2)
+                const int tiles = (n1 + n2) * tiles_n;
+                int worst = 0;
+                for (int s = 0; s < slots && s < tiles; ++s) {
+                    int load = 0;
+                    for (int l = s; l < tiles; l += slots) load += (l / tiles_n) < n1 ? a : b;
+                    worst = load > worst ? load : worst;
+                }
+                if (worst < best) { best = worst; ha = a; na = n1; hb = b; nb = n2; }
+            }
+    return best;
+}
+
 // tile height (in 16-row units) that minimises rounds x height, rounds = ceil(tiles / cus)
-inline PipePlan make_plan(const GemmArgs& a, int cus) {
+inline PipePlan make_plan(const GemmArgs& a, int cus, bool allow_mixed = false) {
     PipePlan pl;
+    pl.mixed = 0; pl.xcd_units = 0; pl.ha = pl.na = pl.hb = pl.nb = 0;
     pl.tiles_n = a.N / BN;
     int best = 16;
     long best_cost = -1;
@@ -56,6 +94,30 @@ inline PipePlan make_plan(const GemmArgs& a, int cus) {
     }
     if ((a.order & 15) == 1) pl.gn = 0;
     if ((a.order & 15) == 3) pl.gn = (a.order >> 4) & 15;
+    // Few n-tiles (plain order) and at least one tile per workgroup: the two-height plan, where it leaves the busiest
+    // workgroup fewer m-tiles than equal tiles do.  Found by exhaustive search, so remembered per shape.
+    if (allow_mixed && pl.gn == 0 && !(forced >= 1 && forced <= 16) && ((a.order >> 13) & 1) == 0 && cus % 8 == 0 &&
+        (long)pl.tiles_m * pl.tiles_n >= cus && a.M <= (1 << 17)) {
+        struct Memo { int M, tiles_n, cus, worst, ha, na, hb, nb; };
+        static thread_local Memo memo[8];
+        static thread_local int memo_n = 0;
+        const Memo* hit = nullptr;
+        for (int i = 0; i < memo_n; ++i)
+            if (memo[i].M == a.M && memo[i].tiles_n == pl.tiles_n && memo[i].cus == cus) hit = &memo[i];
+        const int units = ((a.M + 15) / 16 + 7) / 8;                 // m-tiles per XCD
+        if (!hit) {
+            Memo m = {a.M, pl.tiles_n, cus, 0, 0, 0, 0, 0};
+            m.worst = plan_two_heights(units, pl.tiles_n, cus / 8, 10, m.ha, m.na, m.hb, m.nb);   // heights as the equal-tile plan's: below 160 rows the LDS-DMA feed binds
+            const int at = memo_n < 8 ? memo_n++ : 7;
+            memo[at] = m;
+            hit = &memo[at];
+        }
+        const long uniform = (((long)pl.tiles_m * pl.tiles_n + cus - 1) / cus) * pl.mtot;
+        if (hit->worst < uniform) {
+            pl.mixed = 1; pl.xcd_units = units;
+            pl.ha = hit->ha; pl.na = hit->na; pl.hb = hit->hb; pl.nb = hit->nb;
+        }
+    }
     return pl;
 }
 

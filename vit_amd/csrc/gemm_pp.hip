@@ -65,18 +65,24 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_pp(const GemmArgs p
     const int slots = ((int)gridDim.x - xcd + 7) >> 3;
     const int cq = total_tiles >> 3, cr = total_tiles & 7;
     const int chunk0 = xcd * cq + (xcd < cr ? xcd : cr);
-    const int chunk_n = cq + (xcd < cr ? 1 : 0);
+    const int chunk_n = pl.mixed ? (pl.na + pl.nb) * pl.tiles_n : cq + (xcd < cr ? 1 : 0);
     const int my_tiles = slot < chunk_n ? (chunk_n - slot + slots - 1) / slots : 0;
     if (my_tiles == 0) return;                                   // whole workgroup leaves together
 
     const int ktiles = p.K / BK;
     const int total_classes = my_tiles * ktiles * 4;
-    const int bme = pl.mtot * 16;
     const int grp = wave >> 2, wn = wave & 3;
-    const int mt0 = (pl.mtot + 1) >> 1;                          // m-tiles of group 0
-    const int rows_g0 = mt0 * 16, rows_g1 = (pl.mtot - mt0) * 16;
-    const int my_mt = grp ? pl.mtot - mt0 : mt0;                 // 4..8 (the launcher keeps mtot >= 8)
-    const int my_row0 = grp ? rows_g0 : 0;
+    // tile i of this workgroup -> first row, height in m-tiles (8..16: a group has 4..8), n-tile
+    auto tile_geo = [&](int i, int& m_first, int& mtot, int& tile_n) {
+        if (pl.mixed) {
+            mixed_tile(pl, xcd, slot + i * slots, m_first, mtot, tile_n);
+        } else {
+            int tm;
+            tile_coords(pl, chunk0 + slot + i * slots, tm, tile_n);
+            mtot = pl.mtot;
+            m_first = tm * mtot * 16;
+        }
+    };
 
     constexpr int kAStage = 2 * 128 * kRowBytes;                 // 32 KiB: both groups' rows of one stage
     constexpr int kWRegion = 2 * kAStage;                        // W stages follow the two A stages
@@ -91,10 +97,11 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_pp(const GemmArgs p
     const uint32_t w_half = (uint32_t)((size_t)128 * p.K * 2);   // 128 weight rows further down
     int iss_c = 0, iss_buf = 0, iss_kt = 0, iss_tile = 0;
     uint32_t a_off[2][2], w_off[2];                              // [upper / lower half][group], [first / last n-tiles]
-    auto tile_offsets = [&](int tile_index) {
-        int tm, tn;
-        tile_coords(pl, tile_index, tm, tn);
-        const int m_first = tm * bme, n_first = tn * BN;
+    auto tile_offsets = [&](int i) {
+        int m_first, mtot, tn;
+        tile_geo(i, m_first, mtot, tn);
+        const int n_first = tn * BN;
+        const int rows_g0 = ((mtot + 1) >> 1) * 16, rows_g1 = (mtot - ((mtot + 1) >> 1)) * 16;
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh) {
             const int piece = mh * 64 + wave * 8;                // first group-local row of this wave's piece
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_pp(const GemmArgs p
             w_off[nh] = (uint32_t)(n_first + piece + srow) * (uint32_t)(p.K * 2) + schunk * 16;
         }
     };
-    tile_offsets(chunk0 + slot);
+    tile_offsets(0);
     // one class (J = 0..3 as listed above) of the stream: 2 DMA instructions per wave, always
     auto issue_class = [&](auto jc) {
         constexpr int J = decltype(jc)::value;
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_pp(const GemmArgs p
             iss_buf ^= 1;
             if (++iss_kt == ktiles) {
                 iss_kt = 0;
-                if (++iss_tile < my_tiles) tile_offsets(chunk0 + slot + iss_tile * slots);
+                if (++iss_tile < my_tiles) tile_offsets(iss_tile);
             }
         }
     };
@@ -191,6 +198,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_pp(const GemmArgs p
 
     bf16x8 af[4][2], wf0[2][2], wf1[2][2];
     f32x4 acc[4][8];
+    int my_mt = 8;                            // m-tiles of this wave's group in the current output tile (4..8)
 
     auto load_w = [&](bf16x8 (&wf)[2][2], auto stc, int nh) {
         constexpr int stage = decltype(stc)::value;
@@ -318,9 +326,12 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_pp(const GemmArgs p
 
     char* win = smem + 2 * kStageBytes + wave * kEpiBytesPerWave;
     for (int t = 0; t < my_tiles; ++t) {
-        int tm, tn;
-        tile_coords(pl, chunk0 + slot + t * slots, tm, tn);
-        const int m0 = tm * bme, n0 = tn * BN;
+        int m0, mtot_t, tn;
+        tile_geo(t, m0, mtot_t, tn);
+        const int n0 = tn * BN;
+        const int mt0 = (mtot_t + 1) >> 1;                       // m-tiles of group 0
+        my_mt = grp ? mtot_t - mt0 : mt0;
+        const int my_row0 = grp ? mt0 * 16 : 0;
         if (grp) __builtin_amdgcn_s_barrier();                   // group 1 falls one barrier behind
 
         // K/64 is even, so every output tile starts in stage 0.  The first K tile's first k-step takes 0 as
@@ -358,7 +369,10 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_pp(const GemmArgs p
 
         // ---- epilogue, both groups together (the next tile's first K tiles are in flight or landed)
         const int mw = m0 + my_row0, nw = n0 + wn * 64;
-        int row_limit = p.M - mw;
+        // rows end at M, and in the two-height plan at the end of the XCD's row range (its last panel may reach past it)
+        int m_end = p.M;
+        if (pl.mixed) m_end = m_end < (xcd + 1) * pl.xcd_units * 16 ? m_end : (xcd + 1) * pl.xcd_units * 16;
+        int row_limit = m_end - mw;
         row_limit = row_limit < my_mt * 16 ? row_limit : my_mt * 16;
         // An opaque copy of the lane id: everything the epilogue derives from it is then computed
         // here, per tile, instead of being hoisted above the K loop and held (or spilled) across it.
@@ -384,7 +398,7 @@ static hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
     const int cus = num_cus();
     GemmArgs b = a;
     if (((b.order >> 8) & 31) >= 1 && ((b.order >> 8) & 31) < 8) b.order = (b.order & ~(31 << 8)) | (8 << 8);
-    const PipePlan pl = make_plan(b, cus);
+    const PipePlan pl = make_plan(b, cus, true);
     const int tiles = pl.tiles_m * pl.tiles_n;
     const int grid = tiles < cus ? tiles : cus;
 #ifdef VITK_PROBES                                   // timing probes (wrong or no results): diagnostic builds only

@@ -35,10 +35,12 @@ def main():
         x = torch.randn(R, N, device="cuda").to(torch.bfloat16)
         out = torch.empty(M, N, dtype=torch.float32, device="cuda")
         fl = 2.0 * R * M * N
+        cs = torch.empty(M, device="cuda")
         t_own = timeit(lambda: ops.gemm_tn(g, x, out))
+        t_cs = timeit(lambda: ops.gemm_tn(g, x, out, colsum=cs))
         t_lib = timeit(lambda: g.t() @ x)
-        print(f"R={R} M={M} N={N}: vitk_gemm_tn {t_own:8.1f} us {fl / t_own / 1e6:7.1f} TFLOP/s | torch {t_lib:8.1f} us "
-              f"{fl / t_lib / 1e6:7.1f} TFLOP/s", flush=True)
+        print(f"R={R} M={M} N={N}: vitk_gemm_tn {t_own:8.1f} us {fl / t_own / 1e6:7.1f} TFLOP/s, with column sums {t_cs:8.1f} us "
+              f"| torch {t_lib:8.1f} us {fl / t_lib / 1e6:7.1f} TFLOP/s", flush=True)
 
 
 if __name__ == "__main__":

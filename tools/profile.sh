@@ -14,7 +14,7 @@ fatal() { case "$1" in 124|134|137|139) echo "step '$2' ended with $1: stopping"
 
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- \
     python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --arch $ARCH --img-size $IMG --batch $BATCH > $OUT/bench_under_rocprof.log 2>&1
-rc=$?; tail -n 1 $OUT/bench_under_rocprof.log > $OUT/bench_line_under_rocprof.json; echo "kernel-trace rc=$rc"; fatal $rc trace
+rc=$?; grep "^{" $OUT/bench_under_rocprof.log | tail -n 1 > $OUT/bench_line_under_rocprof.json; echo "kernel-trace rc=$rc"; fatal $rc trace
 
 i=0
 for pmc in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" \

@@ -245,6 +245,14 @@ int vitk_gemm_grad_act(const void* G, const void* Wt, const void* aux, void* out
  * min(partial_rows, 256) row chunks are summed separately and added in a fixed order. */
 int vitk_colsum_bf16(const void* G, float* out, float* partials, int partial_rows, int R, int M, void* stream);
 
+/* Diagnostic: the tile plan the tiled GEMM would use for out[M,N] = A[M,K] W[N,K]^T on a device with `cus` compute
+ * units (0 = the current device's, 256 without a device), without launching anything.  plan[10] = {m-tiles per
+ * tile, tiles along M, tiles along N, n-group width of the tile order (0 = none), two-height plan in use (0/1),
+ * m-tiles per XCD, ha, na, hb, nb} (two-height plan: an XCD's rows are cut into na panels of ha m-tiles followed
+ * by nb panels of hb; all 0 otherwise).  An m-tile is 16 rows.  No counterpart in the reference: the planner is
+ * host logic of this library, exposed so that it can be tested without a GPU. */
+int vitk_gemm_plan(int M, int N, int K, int cus, int* plan);
+
 /* ---- for callers that cannot allocate ------------------------------------------------------------- */
 
 /* Optional set-up for the current device: resolves the library's built-in scratch (used by

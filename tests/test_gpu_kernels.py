@@ -270,7 +270,7 @@ def test_unsupported_head_dim_raises():
 
 # ----------------------------------------------------------------------------- full-size launches
 @pytest.mark.parametrize("M,N,K", [(50432, 768, 768), (50432 + 77, 768, 768), (50432, 1024, 1024), (73856, 768, 768),
-                                   (50432, 768, 3072), (40000, 512, 256)])
+                                   (50432, 768, 3072), (40000, 512, 256), (55065, 1280, 256), (34566, 2560, 128)])
 def test_gemm_tile_plans_at_full_size(M, N, K):
     """Shapes with at least one output tile per CU and few n-tiles take the two-height tile plan (an XCD's rows cut
     into tall panels, then shorter ones): every element against a torch product on the GPU, and bit-identical to the

@@ -108,7 +108,7 @@ inline PipePlan make_plan(const GemmArgs& a, int cus, bool allow_mixed = false) 
     }
     if ((a.order & 15) == 1) pl.gn = 0;
     if ((a.order & 15) == 3) pl.gn = (a.order >> 4) & 15;
-    // Few n-tiles (plain order) and at least one tile per workgroup: the two-height plan, where it leaves the busiest
+    // Plain tile order (few n-tiles, or small K) and at least one tile per workgroup: the two-height plan, where it leaves the busiest
     // workgroup fewer m-tiles than equal tiles do.  Found by exhaustive search, so remembered per shape.
     if (allow_mixed && pl.gn == 0 && !(forced >= 1 && forced <= 16) && ((a.order >> 13) & 1) == 0 && cus % 8 == 0 &&
         (long)pl.tiles_m * pl.tiles_n >= cus && a.M <= (1 << 17)) {

@@ -5,6 +5,7 @@
 #include <stdio.h>
 
 #include "../../include/vitk.h"
+#include "gemm_plan.h"
 #include "vitk_kernels.h"
 
 using namespace vitk;
@@ -61,7 +62,7 @@ int dense(const char* name, const void* A, const void* W, const float* bias, con
 
 extern "C" {
 
-int vitk_version(void) { return 5; }
+int vitk_version(void) { return 6; }
 
 const char* vitk_last_error(void) { return g_err; }
 
@@ -420,6 +421,18 @@ int vitk_colsum_bf16(const void* G, float* out, float* partials, int partial_row
         return fail(VITK_ERR_INVALID, "vitk_colsum_bf16: pointers must be 16-byte aligned");
     return launched(launch_colsum_bf16(G, out, partials, partial_rows, R, M, reinterpret_cast<hipStream_t>(stream)),
                     "vitk_colsum_bf16");
+}
+
+int vitk_gemm_plan(int M, int N, int K, int cus, int* plan) {
+    if (!plan) return fail(VITK_ERR_INVALID, "vitk_gemm_plan: null pointer");
+    if (M <= 0 || N <= 0 || K <= 0 || N % 256 != 0 || K % 64 != 0 || cus < 0)
+        return fail(VITK_ERR_UNSUPPORTED, "vitk_gemm_plan: M=%d N=%d K=%d (N a multiple of 256, K of 64)", M, N, K);
+    GemmArgs a = {};
+    a.M = M; a.N = N; a.K = K;
+    const PipePlan pl = make_plan(a, cus > 0 ? cus : num_cus(), gemm_pp_supports(a, false));
+    const int out[10] = {pl.mtot, pl.tiles_m, pl.tiles_n, pl.gn, pl.mixed, pl.xcd_units, pl.ha, pl.na, pl.hb, pl.nb};
+    for (int i = 0; i < 10; ++i) plan[i] = out[i];
+    return VITK_OK;
 }
 
 int vitk_init(void) {

@@ -271,7 +271,7 @@ def main():
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if a.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"ViT-{a.arch.upper()[0]}/{cfg['patches']} {a.img_size}px "
-                                   + ("forward, " if a.mode == "fwd" else "training step (fwd kernels + torch backward, CE, clip 1.0, AdamW), ")
+                                   + ("forward, " if a.mode == "fwd" else "training step (forward and backward kernels of the library; CE, clip 1.0, AdamW from torch), ")
                                    + f"batch {a.batch} per GPU, random-init weights"
                                    + (" (BASELINE configs[1])" if (a.mode, a.arch, a.img_size, a.batch) == ("fwd", "b16", 224, 256) else ""),
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world, "tokens": ntok,

@@ -1,0 +1,160 @@
+// How fast can a CU pull L2-resident data into LDS, and what do LDS reads beside it cost?  Per wave and iteration:
+//   0: 4 x global_load_lds_dwordx4 (LDS-DMA, 1 KB each)     1: 4 x global_load_dwordx4 -> VGPR -> ds_write_b128
+//   2: 4 x global_load_dwordx4 -> VGPR only (no LDS)        3: 24 x ds_read_b64_tr_b16 (512 B each)
+//   4: 0 and 3 together                                      5: 12 x ds_read_b128 (1 KB each)
+//   6: 0 and 5 together                                      7: 32 x v_mfma_f32_16x16x32_bf16 (independent accumulators)
+//   8: 0, 3 and 7 together, nothing depending on anything   9: 3 and 7     10: 0 and 7     11: 5 and 7
+// 256 workgroups of 8 waves (one per CU), each wave keeps DEPTH batches of 4 instructions in flight over a
+// window small enough to stay in its XCD's L2.  Prints bytes per clock per CU from the shader clock counter.
+//
+//   hipcc -O3 --offload-arch=gfx950 tools/dma_probe.hip -o tools/dma_probe && tools/dma_probe
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int MODE, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void probe(const char* __restrict__ src, size_t window, int iters,
+                                                     unsigned long long* __restrict__ cycles, uint32_t* __restrict__ sink) {
+    __shared__ __attribute__((aligned(1024))) char smem[WAVES * 4 * 1024 * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const char* base = src + (size_t)(blockIdx.x & 7) * window;   // an XCD's workgroups share a window
+    const size_t per_iter = (size_t)WAVES * 4 * 1024;
+    const size_t n_pos = window / per_iter;
+    u32x4 keep = {0, 0, 0, 0};
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 acc[32];
+    for (int i = 0; i < 32; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const u32x4 fu = {0x3F803F80u + (uint32_t)tid, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    const bf16x8 fa = __builtin_bit_cast(bf16x8, fu), fb = fa;
+    __syncthreads();
+    const unsigned long long t0 = clock64();
+    size_t pos = (blockIdx.x >> 3) % n_pos;
+    for (int it = 0; it < iters; ++it) {
+        const char* p = base + pos * per_iter + (size_t)wave * 4096 + lane * 16;
+        char* d = smem + (it & 1) * WAVES * 4096 + wave * 4096;
+        if constexpr (MODE == 0 || MODE == 4 || MODE == 6 || MODE == 8 || MODE == 10) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((gbl_void*)(p + i * 1024), (lds_void*)(d + i * 1024), 16, 0, 0);
+        }
+        if constexpr (MODE == 3 || MODE == 4 || MODE == 8 || MODE == 9) {
+            // the address pattern of the weight-gradient GEMM's fragment reads (conflict-free, 512-byte rows)
+            const int q = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3, fl = tq | ((q & 1) << 2);
+            const uint32_t a0 = (uint32_t)(uintptr_t)(lds_void*)smem + (uint32_t)((8 * q + tq) * 512 + tp * 8);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                uint64_t r0, r1;
+                const uint32_t a = a0 + (uint32_t)((((wave + i) & 15) ^ fl) << 5);
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r0) : "v"(a));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(r1) : "v"(a));
+                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(r0), "+v"(r1));
+                keep[0] ^= (uint32_t)r0 ^ (uint32_t)r1;
+            }
+        }
+        if constexpr (MODE == 5 || MODE == 6 || MODE == 11) {
+            const uint32_t a0 = (uint32_t)(uintptr_t)(lds_void*)smem + (uint32_t)(lane * 16);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                u32x4 r;
+                const uint32_t a = a0 + (uint32_t)(((wave + i) & 15) << 10);
+                asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(a));
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(r));
+                keep[0] ^= r[0];
+            }
+        }
+        if constexpr (MODE >= 7) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[i], 0, 0, 0);
+        }
+        if constexpr (MODE == 0 || MODE == 4 || MODE == 6 || MODE == 8 || MODE == 10) {
+            __builtin_amdgcn_s_waitcnt(0x0F74);   // vmcnt(4): the previous batch has landed
+        } else if constexpr (MODE == 1 || MODE == 2) {
+            u32x4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const u32x4*>(p + i * 1024);
+            if constexpr (MODE == 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t a = (uint32_t)(uintptr_t)(lds_void*)(d + i * 1024 + lane * 16);
+                    asm volatile("ds_write_b128 %0, %1" : : "v"(a), "v"(v[i]) : "memory");
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) keep ^= v[i];
+            }
+        }
+        pos = pos + 1 == n_pos ? 0 : pos + 1;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    const unsigned long long t1 = clock64();
+    if (MODE != 2) keep[1] ^= reinterpret_cast<uint32_t*>(smem)[tid];
+    if (tid == 0) cycles[blockIdx.x] = t1 - t0;
+    if constexpr (MODE >= 7) {
+        float t = 0.f;
+        for (int i = 0; i < 32; ++i) t += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+        if (t == 12345.f) sink[1] = 1;
+    }
+    if (keep[0] == 0x12345678u) sink[0] = keep[1] ^ keep[2] ^ keep[3];
+}
+
+template <int MODE, int WAVES>
+void run(const char* label, const char* src, size_t window, unsigned long long* cyc, uint32_t* sink) {
+    const int iters = 4000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL((probe<MODE, WAVES>), dim3(256), dim3(WAVES * 64), 0, 0, src, window, iters, cyc, sink);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((probe<MODE, WAVES>), dim3(256), dim3(WAVES * 64), 0, 0, src, window, iters, cyc, sink);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(256);
+    hipMemcpy(h.data(), cyc, 256 * 8, hipMemcpyDeviceToHost);
+    double mean = 0;
+    for (auto c : h) mean += (double)c / 256;
+    const double bytes = (double)iters * WAVES * 4096;
+    // (the byte figures count 4 KB per wave and iteration: the LDS-DMA / global load volume of the modes that have one)
+    printf("%-44s %2d waves: %7.3f ms, %7.0f clocks per iteration, %5.2f GHz, %6.1f B/clk/CU, %6.2f TB/s aggregate\n", label, WAVES, ms,
+           mean / iters, mean / (ms * 1e6), bytes / mean, bytes * 256 / (ms * 1e-3) / 1e12);
+}
+
+int main() {
+    const size_t window = 2u << 20;   // 2 MB per XCD: L2-resident
+    char* src;
+    unsigned long long* cyc;
+    uint32_t* sink;
+    hipMalloc(&src, 8 * window);
+    hipMemset(src, 1, 8 * window);
+    hipMalloc(&cyc, 256 * 8);
+    hipMalloc(&sink, 64);
+    run<3, 8>("24 ds_read_b64_tr_b16", src, window, cyc, sink);
+    run<4, 8>("LDS-DMA + 24 ds_read_b64_tr_b16", src, window, cyc, sink);
+    run<5, 8>("12 ds_read_b128", src, window, cyc, sink);
+    run<6, 8>("LDS-DMA + 12 ds_read_b128", src, window, cyc, sink);
+    run<7, 8>("32 MFMA", src, window, cyc, sink);
+    run<9, 8>("32 MFMA + 24 ds_read_b64_tr_b16", src, window, cyc, sink);
+    run<11, 8>("32 MFMA + 12 ds_read_b128", src, window, cyc, sink);
+    run<10, 8>("32 MFMA + LDS-DMA", src, window, cyc, sink);
+    run<8, 8>("32 MFMA + LDS-DMA + 24 ds_read_b64_tr_b16", src, window, cyc, sink);
+    run<0, 8>("LDS-DMA (global_load_lds_dwordx4)", src, window, cyc, sink);
+    run<1, 8>("global_load_dwordx4 + ds_write_b128", src, window, cyc, sink);
+    run<2, 8>("global_load_dwordx4 only", src, window, cyc, sink);
+    run<0, 4>("LDS-DMA (global_load_lds_dwordx4)", src, window, cyc, sink);
+    run<1, 4>("global_load_dwordx4 + ds_write_b128", src, window, cyc, sink);
+    run<2, 4>("global_load_dwordx4 only", src, window, cyc, sink);
+    run<0, 16>("LDS-DMA (global_load_lds_dwordx4)", src, window, cyc, sink);
+    run<1, 16>("global_load_dwordx4 + ds_write_b128", src, window, cyc, sink);
+    if (hipGetLastError() != hipSuccess) { printf("HIP error\n"); return 1; }
+    return 0;
+}

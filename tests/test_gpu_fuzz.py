@@ -1,7 +1,11 @@
 """Seeded random shapes through the C ABI: the hand-picked shapes of test_gpu_kernels.py are the models' own; these
 sweep what lies between them (tile edges, ragged rows, odd token counts, every kernel-selection boundary) against
 plain torch arithmetic on the same bf16-rounded operands (fp32 / fp64 on the GPU).  Tolerances as in
-test_gpu_kernels.py: fp32 summation order and one bf16 rounding on store."""
+test_gpu_kernels.py: fp32 summation order and one bf16 rounding on store.
+
+VITK_FUZZ_SEED=s (non-zero) draws other cases, from ranges instead of the lists of edge values, and VITK_FUZZ_MULT=m
+draws m times as many: for sweeps beyond the suite (`VITK_FUZZ_SEED=5 VITK_FUZZ_MULT=4 pytest tests/test_gpu_fuzz.py`)."""
+import os
 import random
 
 import pytest
@@ -12,6 +16,8 @@ from vit_amd import lib, ops
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+SEED = int(os.environ.get("VITK_FUZZ_SEED", "0"))
+MULT = int(os.environ.get("VITK_FUZZ_MULT", "1"))
 
 
 def _gemm_shapes(n, seed):
@@ -21,6 +27,8 @@ def _gemm_shapes(n, seed):
         kind = rng.random()
         if kind < 0.6:          # tiled kernels: N multiple of 256, K of 64, any M >= 128
             M = rng.choice([128, 129, 255, 256, 257, 300, 511, 1000, 1576, 2047, 3000, 4099, 6500])
+            if SEED:
+                M = rng.randint(128, 9000)
             N = 256 * rng.randint(1, 6)
             K = 64 * rng.randint(1, 24)
         else:                   # small kernel: anything with K % 32 == 0
@@ -39,7 +47,7 @@ def _operands(M, N, K, seed):
     return a, w, b
 
 
-@pytest.mark.parametrize("M,N,K", _gemm_shapes(36, 1))
+@pytest.mark.parametrize("M,N,K", _gemm_shapes(36 * MULT, 1 + SEED))
 def test_fuzz_gemm_epilogues(M, N, K):
     a, w, b = _operands(M, N, K, M * 7 + N + K)
     acc = a.float() @ w.float().t() + b
@@ -76,6 +84,8 @@ def _attn_cases(n, seed):
         hd = rng.choice([64, 64, 64, 80, 96])
         N = rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 100, 160, 161, 196, 197, 255, 256, 257, 288, 289, 320, 400, 576, 577,
                         608, 609, 700, 1000])
+        if SEED:
+            N = rng.randint(1, 1100)
         B, H = rng.randint(1, 3), rng.randint(1, 5)
         if N > 600:
             B, H = 1, rng.randint(1, 2)
@@ -83,7 +93,7 @@ def _attn_cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("B,H,N,hd", _attn_cases(40, 2))
+@pytest.mark.parametrize("B,H,N,hd", _attn_cases(40 * MULT, 2 + SEED))
 def test_fuzz_attention(B, H, N, hd):
     g = torch.Generator(device=DEV).manual_seed(B * 100000 + H * 10000 + N * 10 + hd)
     qkv = torch.randn(3, B, H, N, hd, generator=g, device=DEV).to(torch.bfloat16)
@@ -110,7 +120,7 @@ def _tn_shapes(n, seed):
     return [(64 * rng.randint(1, 200), 256 * rng.randint(1, 5), 256 * rng.randint(1, 5)) for _ in range(n)]
 
 
-@pytest.mark.parametrize("R,M,N", _tn_shapes(10, 3))
+@pytest.mark.parametrize("R,M,N", _tn_shapes(10 * MULT, 3 + SEED))
 def test_fuzz_weight_gradient_gemm_with_column_sums(R, M, N):
     g = torch.Generator(device=DEV).manual_seed(R + M + N)
     gd = (torch.randn(R, M, generator=g, device=DEV) * 0.5).to(torch.bfloat16)
@@ -158,7 +168,7 @@ def _model_cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("case", _model_cases(12, 4), ids=lambda c: f"P{c['patches']}_D{c['hidden_size']}_H{c['num_heads']}_img{c['img']}")
+@pytest.mark.parametrize("case", _model_cases(12 * MULT, 4 + SEED), ids=lambda c: f"P{c['patches']}_D{c['hidden_size']}_H{c['num_heads']}_img{c['img']}")
 def test_fuzz_whole_model_against_the_oracle(case):
     """Random configurations of the module (patch sizes through both patch-embedding routes, head sizes 64 / 80 / 96,
     image sizes that leave a border the convolution ignores, with and without pre_logits) in both compute modes

@@ -14,6 +14,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """VITK_TEST_ORDER=reverse / a number: run the collected tests backwards / shuffled with that seed (tests must not
+    depend on what ran before them: cached scratch buffers, debug variants, the weight cache)."""
+    order = os.environ.get("VITK_TEST_ORDER", "")
+    if order == "reverse":
+        items.reverse()
+    elif order:
+        import random
+        random.Random(int(order)).shuffle(items)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

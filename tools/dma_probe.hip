@@ -12,6 +12,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -35,7 +36,8 @@ __global__ __launch_bounds__(WAVES * 64) void probe(const char* __restrict__ src
     const bf16x8 fa = __builtin_bit_cast(bf16x8, fu), fb = fa;
     __syncthreads();
     const unsigned long long t0 = clock64();
-    size_t pos = (blockIdx.x >> 3) % n_pos;
+    // a small window is shared by the XCD's workgroups (L2 hits); in a large one every workgroup walks a range of its own
+    size_t pos = window > (16u << 20) ? (size_t)(blockIdx.x >> 3) * (n_pos / 32) : (blockIdx.x >> 3) % n_pos;
     for (int it = 0; it < iters; ++it) {
         const char* p = base + pos * per_iter + (size_t)wave * 4096 + lane * 16;
         char* d = smem + (it & 1) * WAVES * 4096 + wave * 4096;
@@ -129,8 +131,9 @@ void run(const char* label, const char* src, size_t window, unsigned long long* 
            mean / iters, mean / (ms * 1e6), bytes / mean, bytes * 256 / (ms * 1e-3) / 1e12);
 }
 
-int main() {
-    const size_t window = 2u << 20;   // 2 MB per XCD: L2-resident
+int main(int argc, char** argv) {
+    // window per XCD in MB: 2 (default) stays in L2; 512 streams from HBM (every line is new)
+    const size_t window = (size_t)(argc > 1 ? atoi(argv[1]) : 2) << 20;
     char* src;
     unsigned long long* cyc;
     uint32_t* sink;

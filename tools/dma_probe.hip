@@ -107,33 +107,37 @@ __global__ __launch_bounds__(WAVES * 64) void probe(const char* __restrict__ src
     if (keep[0] == 0x12345678u) sink[0] = keep[1] ^ keep[2] ^ keep[3];
 }
 
+static int g_grid = 256;   // workgroups (one per CU up to 256)
+
 template <int MODE, int WAVES>
 void run(const char* label, const char* src, size_t window, unsigned long long* cyc, uint32_t* sink) {
     const int iters = 4000;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    hipLaunchKernelGGL((probe<MODE, WAVES>), dim3(256), dim3(WAVES * 64), 0, 0, src, window, iters, cyc, sink);
+    hipLaunchKernelGGL((probe<MODE, WAVES>), dim3(g_grid), dim3(WAVES * 64), 0, 0, src, window, iters, cyc, sink);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL((probe<MODE, WAVES>), dim3(256), dim3(WAVES * 64), 0, 0, src, window, iters, cyc, sink);
+    hipLaunchKernelGGL((probe<MODE, WAVES>), dim3(g_grid), dim3(WAVES * 64), 0, 0, src, window, iters, cyc, sink);
     hipEventRecord(e1);
     hipDeviceSynchronize();
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
-    std::vector<unsigned long long> h(256);
-    hipMemcpy(h.data(), cyc, 256 * 8, hipMemcpyDeviceToHost);
+    std::vector<unsigned long long> h(g_grid);
+    hipMemcpy(h.data(), cyc, g_grid * 8, hipMemcpyDeviceToHost);
     double mean = 0;
-    for (auto c : h) mean += (double)c / 256;
+    for (auto c : h) mean += (double)c / g_grid;
     const double bytes = (double)iters * WAVES * 4096;
     // (the byte figures count 4 KB per wave and iteration: the LDS-DMA / global load volume of the modes that have one)
     printf("%-44s %2d waves: %7.3f ms, %7.0f clocks per iteration, %5.2f GHz, %6.1f B/clk/CU, %6.2f TB/s aggregate\n", label, WAVES, ms,
-           mean / iters, mean / (ms * 1e6), bytes / mean, bytes * 256 / (ms * 1e-3) / 1e12);
+           mean / iters, mean / (ms * 1e6), bytes / mean, bytes * g_grid / (ms * 1e-3) / 1e12);
 }
 
 int main(int argc, char** argv) {
     // window per XCD in MB: 2 (default) stays in L2; 512 streams from HBM (every line is new)
     const size_t window = (size_t)(argc > 1 ? atoi(argv[1]) : 2) << 20;
+    if (argc > 2) g_grid = atoi(argv[2]);   // fewer workgroups: what one CU can pull when the others are quiet
+    if (g_grid < 8 || g_grid > 256) return 2;
     char* src;
     unsigned long long* cyc;
     uint32_t* sink;

@@ -59,7 +59,8 @@ const char* vitk_last_error(void);
  *   160 at 80 / 96; one head per workgroup when one fits: ntok <= 608 / 288; else streamed), 1 = one head
  *   per workgroup with V stored transposed (head_dim 64), 2 = K/V streamed through LDS in 64-key chunks,
  *   3 = one head per workgroup; bits 5-8 force the waves per workgroup (4..8; 10 and, at head_dim 64 with one
- *   head per workgroup, 12 in the resident modes; 0 = chosen from the token count); diagnostic builds only:
+ *   head per workgroup, 12 in the resident modes; 0 = chosen from the token count); bit 9 = the attention backward
+ *   as two kernels (dQ, then dK / dV) also where the one-kernel form applies (ntok <= 288); diagnostic builds only:
  *   bit 2 = K/V of head 0 for every head, bit 3 = no key loop, bit 4 = no output stores.
  * Results are identical across variants up to fp32 summation order. */
 void vitk_set_debug_variant(int gemm_variant, int attention_variant);

@@ -272,6 +272,14 @@ def test_gpu_attention_backward_more_heads_than_compute_units(B, H, N):
     ref = want.abs().max()
     assert float(err.max()) <= 2e-2 * float(ref) + 1e-3, f"worst head {err.max():.3e} (gradient magnitude {ref:.3e})"
     assert torch.equal(got, ops.attention_backward(qkv, ctx, dctx, lse, scale))
+    # up to 288 tokens one kernel does both passes from one LDS image of Q, K, V, dO; the two-kernel form (larger token
+    # counts; here forced by the debug variant) computes the same sums in the same order
+    from vit_amd import lib
+    try:
+        lib.load().vitk_set_debug_variant(0, 0x200)
+        assert torch.equal(got, ops.attention_backward(qkv, ctx, dctx, lse, scale))
+    finally:
+        lib.load().vitk_set_debug_variant(0, 0)
     for b in (0, B // 2, B - 1):                                            # a launch with few heads: one head per workgroup
         alone = ops.attention_backward(qkv[:, b:b + 1].contiguous(), ctx[b:b + 1].contiguous(), dctx[b:b + 1].contiguous(),
                                        lse[b:b + 1].contiguous(), scale)

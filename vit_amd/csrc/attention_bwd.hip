@@ -36,85 +36,21 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_b;
 typedef __attribute__((address_space(3))) void lds_void_b;
 typedef __attribute__((address_space(1))) const void gbl_void_b;
 
-template <int MODE, int NW>
-__global__ __launch_bounds__(NW * 64) void attention_bwd(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                         const bf16_t* __restrict__ V, const bf16_t* __restrict__ O,
-                                                         const bf16_t* __restrict__ dO, const float* __restrict__ LSE,
-                                                         float* __restrict__ Dbuf, bf16_t* __restrict__ dqkv, int ntok,
-                                                         int heads, float scale) {
+// One owner block (32 queries in MODE 0, 32 keys in MODE 1; the lane's row is orow, its operands t1 / t2) against all
+// resident blocks: accumulates and stores dQ (MODE 0) or dK and dV (MODE 1).  r1 / r2: the resident matrices in LDS
+// (MODE 0: K, V; MODE 1: Q, dO); MODE 0 takes L and D of the lane's query as scalars, MODE 1 reads those of the resident
+// queries from LDS.
+template <int MODE>
+__device__ __forceinline__ void attn_bwd_owner_block(const char* r1, const char* r2, const float* l_lds, const float* d_lds,
+                                                     const bf16x8 (&t1)[4], const bf16x8 (&t2)[4], float Lc, float Dc,
+                                                     int blocks, int ntok, float c, float scale, int orow, int b, int h,
+                                                     int heads, bf16_t* __restrict__ dqkv) {
     constexpr int HD = 64, KS = 4, DB = 2, RB = 128;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bh = blockIdx.x;
-    const int b = bh / heads, h = bh - b * heads;
-    const int blocks = (ntok + 31) >> 5, npad = blocks * 32;
-    const float c = scale * 1.44269504088896340736f;
-    char* r1 = smem;                         // MODE 0: K, MODE 1: Q
-    char* r2 = smem + npad * RB;             // MODE 0: V, MODE 1: dO
-    float* l_lds = reinterpret_cast<float*>(smem + 2 * npad * RB);      // MODE 1: L and D of every query row
-    float* d_lds = l_lds + npad;
-
-    auto swz = [](int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); };
-    const size_t head_rows = (size_t)bh * ntok;              // first row of this head in Q / K / V
-    const size_t ctx_stride = (size_t)heads * HD;            // row stride of O / dO (heads concatenated)
-    const bf16_t* o_head = O + (size_t)b * ntok * ctx_stride + h * HD;
-    const bf16_t* do_head = dO + (size_t)b * ntok * ctx_stride + h * HD;
-
-    // ---- stage the two resident matrices: 8 rows per LDS-DMA instruction (1 KiB), rows past ntok re-read the last
-    {
-        const bf16_t* s1 = (MODE == 0 ? K : Q) + head_rows * HD;
-        const bf16_t* s2 = MODE == 0 ? V + head_rows * HD : do_head;
-        const size_t st2 = MODE == 0 ? HD : ctx_stride;
-        const int pieces = npad / 8;
-        for (int pi = wave; pi < 2 * pieces; pi += NW) {      // wave-uniform
-            const bool second = pi >= pieces;
-            const int lrow = (second ? pi - pieces : pi) * 8 + (lane >> 3);
-            const int chunk = (lane & 7) ^ swz(lrow);
-            const int grow = lrow < ntok ? lrow : ntok - 1;
-            const bf16_t* src = second ? s2 + (size_t)grow * st2 + chunk * 8 : s1 + (size_t)grow * HD + chunk * 8;
-            __builtin_amdgcn_global_load_lds((gbl_void_b*)src, (lds_void_b*)(smem + pi * 1024), 16, 0, 0);
-        }
-        if constexpr (MODE == 1) {
-            for (int i = tid; i < npad; i += NW * 64) {
-                l_lds[i] = i < ntok ? LSE[head_rows + i] : 1.0e30f;        // padded queries: probability 0
-                d_lds[i] = i < ntok ? Dbuf[head_rows + i] : 0.f;
-            }
-        }
-    }
-
+    const int lane = threadIdx.x & 63;
     const int r = lane & 31, hh = lane >> 5;
     const int tsub = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
     const bool ragged = (ntok & 31) != 0;
-    __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
-    __syncthreads();
-
-    for (int o0 = wave * 32; o0 < ntok; o0 += NW * 32) {     // the wave's 32 owner rows (queries / keys)
-        const int orow = o0 + r;
-        const int oc = orow < ntok ? orow : ntok - 1;         // padded rows re-read the last row; never stored
-        bf16x8 t1[KS], t2[KS];
-        float Lc = 0.f, Dc = 0.f;
-        {
-            const bf16_t* p1 = (MODE == 0 ? Q : K) + (head_rows + oc) * HD + hh * 8;
-            const bf16_t* p2 = MODE == 0 ? do_head + (size_t)oc * ctx_stride + hh * 8 : V + (head_rows + oc) * HD + hh * 8;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                t1[ks] = *reinterpret_cast<const bf16x8*>(p1 + ks * 16);
-                t2[ks] = *reinterpret_cast<const bf16x8*>(p2 + ks * 16);
-            }
-            if constexpr (MODE == 0) {
-                const bf16_t* po = o_head + (size_t)oc * ctx_stride + hh * 8;
-                float acc = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const bf16x8 ov = *reinterpret_cast<const bf16x8*>(po + ks * 16);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc += (float)t2[ks][j] * (float)ov[j];
-                }
-                Dc = acc + __shfl_xor(acc, 32, 64);           // the other half-wave holds the other 32 columns
-                Lc = LSE[head_rows + oc];
-                if (hh == 0 && orow < ntok) Dbuf[head_rows + orow] = Dc;
-            }
-        }
+    auto swz = [](int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); };
         f32x16 out1[DB], out2[DB];
 #pragma unroll
         for (int d = 0; d < DB; ++d)
@@ -204,7 +140,194 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd(const bf16_t* __restric
                     }
                 }
         }
+}
+
+template <int MODE, int NW>
+__global__ __launch_bounds__(NW * 64) void attention_bwd(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                         const bf16_t* __restrict__ V, const bf16_t* __restrict__ O,
+                                                         const bf16_t* __restrict__ dO, const float* __restrict__ LSE,
+                                                         float* __restrict__ Dbuf, bf16_t* __restrict__ dqkv, int ntok,
+                                                         int heads, float scale) {
+    constexpr int HD = 64, KS = 4, DB = 2, RB = 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bh = blockIdx.x;
+    const int b = bh / heads, h = bh - b * heads;
+    const int blocks = (ntok + 31) >> 5, npad = blocks * 32;
+    const float c = scale * 1.44269504088896340736f;
+    char* r1 = smem;                         // MODE 0: K, MODE 1: Q
+    char* r2 = smem + npad * RB;             // MODE 0: V, MODE 1: dO
+    float* l_lds = reinterpret_cast<float*>(smem + 2 * npad * RB);      // MODE 1: L and D of every query row
+    float* d_lds = l_lds + npad;
+
+    auto swz = [](int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); };
+    const size_t head_rows = (size_t)bh * ntok;              // first row of this head in Q / K / V
+    const size_t ctx_stride = (size_t)heads * HD;            // row stride of O / dO (heads concatenated)
+    const bf16_t* o_head = O + (size_t)b * ntok * ctx_stride + h * HD;
+    const bf16_t* do_head = dO + (size_t)b * ntok * ctx_stride + h * HD;
+
+    // ---- stage the two resident matrices: 8 rows per LDS-DMA instruction (1 KiB), rows past ntok re-read the last
+    {
+        const bf16_t* s1 = (MODE == 0 ? K : Q) + head_rows * HD;
+        const bf16_t* s2 = MODE == 0 ? V + head_rows * HD : do_head;
+        const size_t st2 = MODE == 0 ? HD : ctx_stride;
+        const int pieces = npad / 8;
+        for (int pi = wave; pi < 2 * pieces; pi += NW) {      // wave-uniform
+            const bool second = pi >= pieces;
+            const int lrow = (second ? pi - pieces : pi) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ swz(lrow);
+            const int grow = lrow < ntok ? lrow : ntok - 1;
+            const bf16_t* src = second ? s2 + (size_t)grow * st2 + chunk * 8 : s1 + (size_t)grow * HD + chunk * 8;
+            __builtin_amdgcn_global_load_lds((gbl_void_b*)src, (lds_void_b*)(smem + pi * 1024), 16, 0, 0);
+        }
+        if constexpr (MODE == 1) {
+            for (int i = tid; i < npad; i += NW * 64) {
+                l_lds[i] = i < ntok ? LSE[head_rows + i] : 1.0e30f;        // padded queries: probability 0
+                d_lds[i] = i < ntok ? Dbuf[head_rows + i] : 0.f;
+            }
+        }
     }
+
+    const int r = lane & 31, hh = lane >> 5;
+    const int tsub = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
+    const bool ragged = (ntok & 31) != 0;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
+    __syncthreads();
+
+    for (int o0 = wave * 32; o0 < ntok; o0 += NW * 32) {     // the wave's 32 owner rows (queries / keys)
+        const int orow = o0 + r;
+        const int oc = orow < ntok ? orow : ntok - 1;         // padded rows re-read the last row; never stored
+        bf16x8 t1[KS], t2[KS];
+        float Lc = 0.f, Dc = 0.f;
+        {
+            const bf16_t* p1 = (MODE == 0 ? Q : K) + (head_rows + oc) * HD + hh * 8;
+            const bf16_t* p2 = MODE == 0 ? do_head + (size_t)oc * ctx_stride + hh * 8 : V + (head_rows + oc) * HD + hh * 8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                t1[ks] = *reinterpret_cast<const bf16x8*>(p1 + ks * 16);
+                t2[ks] = *reinterpret_cast<const bf16x8*>(p2 + ks * 16);
+            }
+            if constexpr (MODE == 0) {
+                const bf16_t* po = o_head + (size_t)oc * ctx_stride + hh * 8;
+                float acc = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 ov = *reinterpret_cast<const bf16x8*>(po + ks * 16);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc += (float)t2[ks][j] * (float)ov[j];
+                }
+                Dc = acc + __shfl_xor(acc, 32, 64);           // the other half-wave holds the other 32 columns
+                Lc = LSE[head_rows + oc];
+                if (hh == 0 && orow < ntok) Dbuf[head_rows + orow] = Dc;
+            }
+        }
+        attn_bwd_owner_block<MODE>(r1, r2, l_lds, d_lds, t1, t2, Lc, Dc, blocks, ntok, c, scale, orow, b, h, heads, dqkv);
+    }
+}
+
+// Both passes in one workgroup per (image, head) for token counts whose Q, K, V and dO fit in LDS together (<= 288):
+// the four matrices are fetched once (8 matrix transfers per head with O and the three gradients, instead of 12), the
+// owner rows' operands come from LDS instead of from global memory, and D goes from the dQ pass to the dK/dV pass through
+// LDS.  Phase A: every wave takes 32 queries against K, V (MODE 0 above); phase B: 32 keys against Q, dO (MODE 1).
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attention_bwd_fused(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                               const bf16_t* __restrict__ V, const bf16_t* __restrict__ O,
+                                                               const bf16_t* __restrict__ dO, const float* __restrict__ LSE,
+                                                               bf16_t* __restrict__ dqkv, int ntok, int heads, float scale) {
+    constexpr int HD = 64, KS = 4, RB = 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bh = blockIdx.x;
+    const int b = bh / heads, h = bh - b * heads;
+    const int blocks = (ntok + 31) >> 5, npad = blocks * 32;
+    const float c = scale * 1.44269504088896340736f;
+    char* qs = smem;
+    char* ks_ = smem + npad * RB;
+    char* vs = smem + 2 * npad * RB;
+    char* dos = smem + 3 * npad * RB;
+    float* l_lds = reinterpret_cast<float*>(smem + 4 * npad * RB);
+    float* d_lds = l_lds + npad;
+    auto swz = [](int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); };
+    const size_t head_rows = (size_t)bh * ntok;
+    const size_t ctx_stride = (size_t)heads * HD;
+    const bf16_t* o_head = O + (size_t)b * ntok * ctx_stride + h * HD;
+    const bf16_t* do_head = dO + (size_t)b * ntok * ctx_stride + h * HD;
+
+    // L first: in front of an LDS store the compiler waits for every LDS-DMA in flight
+    for (int i = tid; i < npad; i += NW * 64) l_lds[i] = i < ntok ? LSE[head_rows + i] : 1.0e30f;   // padded queries: probability 0
+    {
+        const int pieces = npad / 8;                          // per matrix: 8 rows per LDS-DMA instruction (1 KiB)
+        for (int pi = wave; pi < 4 * pieces; pi += NW) {      // wave-uniform
+            const int m = pi / pieces;                        // 0: Q, 1: K, 2: V, 3: dO
+            const int lrow = (pi - m * pieces) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ swz(lrow);
+            const int grow = lrow < ntok ? lrow : ntok - 1;   // rows past ntok re-read the last
+            const bf16_t* src = m == 3 ? do_head + (size_t)grow * ctx_stride + chunk * 8
+                                       : (m == 0 ? Q : m == 1 ? K : V) + (head_rows + grow) * HD + chunk * 8;
+            __builtin_amdgcn_global_load_lds((gbl_void_b*)src, (lds_void_b*)(smem + pi * 1024), 16, 0, 0);
+        }
+    }
+    const int r = lane & 31, hh = lane >> 5;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
+    __syncthreads();
+
+    // ---- phase A: dQ, and D for phase B
+    for (int o0 = wave * 32; o0 < ntok; o0 += NW * 32) {
+        const int orow = o0 + r;
+        const int oc = orow < ntok ? orow : ntok - 1;
+        const int sw = swz(orow);
+        bf16x8 t1[KS], t2[KS];
+        float acc = 0.f;
+        const bf16_t* po = o_head + (size_t)oc * ctx_stride + hh * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            t1[ks] = *reinterpret_cast<const bf16x8*>(qs + orow * RB + (((ks * 2 + hh) ^ sw) << 4));
+            t2[ks] = *reinterpret_cast<const bf16x8*>(dos + orow * RB + (((ks * 2 + hh) ^ sw) << 4));
+            const bf16x8 ov = *reinterpret_cast<const bf16x8*>(po + ks * 16);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += (float)t2[ks][j] * (float)ov[j];
+        }
+        const float Dc = acc + __shfl_xor(acc, 32, 64);       // the other half-wave holds the other 32 columns
+        const float Lc = l_lds[orow];
+        if (hh == 0) d_lds[orow] = orow < ntok ? Dc : 0.f;
+        attn_bwd_owner_block<0>(ks_, vs, l_lds, d_lds, t1, t2, Lc, Dc, blocks, ntok, c, scale, orow, b, h, heads, dqkv);
+    }
+    __syncthreads();                                          // D of every query is in LDS
+
+    // ---- phase B: dK, dV
+    for (int o0 = wave * 32; o0 < ntok; o0 += NW * 32) {
+        const int orow = o0 + r;
+        const int sw = swz(orow);
+        bf16x8 t1[KS], t2[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            t1[ks] = *reinterpret_cast<const bf16x8*>(ks_ + orow * RB + (((ks * 2 + hh) ^ sw) << 4));
+            t2[ks] = *reinterpret_cast<const bf16x8*>(vs + orow * RB + (((ks * 2 + hh) ^ sw) << 4));
+        }
+        attn_bwd_owner_block<1>(qs, dos, l_lds, d_lds, t1, t2, 0.f, 0.f, blocks, ntok, c, scale, orow, b, h, heads, dqkv);
+    }
+}
+
+// Q, K, V, dO and L, D of a head within 160 KiB
+static bool attn_bwd_fits_fused(int ntok) {
+    const int npad = ((ntok + 31) / 32) * 32;
+    return (size_t)4 * npad * 128 + (size_t)2 * npad * 4 <= 160 * 1024;
+}
+
+template <int NW>
+static hipError_t attn_bwd_fused_launch(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                                        const float* lse, void* dqkv, int batch, int heads, int ntok, float scale, hipStream_t s) {
+    const int npad = ((ntok + 31) / 32) * 32;
+    const size_t lds = (size_t)4 * npad * 128 + (size_t)2 * npad * 4;
+    auto kf = &attention_bwd_fused<NW>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kf, dim3(batch * heads), dim3(NW * 64), lds, s, reinterpret_cast<const bf16_t*>(q),
+                       reinterpret_cast<const bf16_t*>(k), reinterpret_cast<const bf16_t*>(v), reinterpret_cast<const bf16_t*>(o),
+                       reinterpret_cast<const bf16_t*>(d_o), lse, reinterpret_cast<bf16_t*>(dqkv), ntok, heads, scale);
+    return hipGetLastError();
 }
 
 int attention_bwd_max_tokens() { return 576; }               // two resident [ntok, 64] bf16 matrices + L, D within 160 KiB
@@ -238,10 +361,19 @@ static hipError_t attn_bwd_launch(const void* q, const void* k, const void* v, c
 
 hipError_t launch_attention_backward(const void* q, const void* k, const void* v, const void* o, const void* d_o,
                                      const float* lse, float* dbuf, void* dqkv, int batch, int heads, int ntok, int hd,
-                                     float scale, hipStream_t s) {
+                                     float scale, int variant, hipStream_t s) {
     if (hd != 64 || ntok < 1 || ntok > attention_bwd_max_tokens()) return hipErrorInvalidValue;
     const int tiles = (ntok + 31) / 32;
     const int nw = attention_pick_waves(tiles, 8);
+    if (attn_bwd_fits_fused(ntok) && !(variant & 0x200)) {   // attention debug variant bit 9: the two-pass kernels at any size
+        switch (nw) {
+            case 4: return attn_bwd_fused_launch<4>(q, k, v, o, d_o, lse, dqkv, batch, heads, ntok, scale, s);
+            case 5: return attn_bwd_fused_launch<5>(q, k, v, o, d_o, lse, dqkv, batch, heads, ntok, scale, s);
+            case 6: return attn_bwd_fused_launch<6>(q, k, v, o, d_o, lse, dqkv, batch, heads, ntok, scale, s);
+            case 7: return attn_bwd_fused_launch<7>(q, k, v, o, d_o, lse, dqkv, batch, heads, ntok, scale, s);
+            default: return attn_bwd_fused_launch<8>(q, k, v, o, d_o, lse, dqkv, batch, heads, ntok, scale, s);
+        }
+    }
     switch (nw) {
         case 4: return attn_bwd_launch<4>(q, k, v, o, d_o, lse, dbuf, dqkv, batch, heads, ntok, scale, s);
         case 5: return attn_bwd_launch<5>(q, k, v, o, d_o, lse, dbuf, dqkv, batch, heads, ntok, scale, s);

@@ -233,7 +233,7 @@ int vitk_attention_backward(const void* q, const void* k, const void* v, const v
     if (ntok > attention_bwd_max_tokens())
         return fail(VITK_ERR_UNSUPPORTED, "vitk_attention_backward: ntok=%d exceeds the limit %d", ntok, attention_bwd_max_tokens());
     return launched(launch_attention_backward(q, k, v, ctx, dctx, lse, dbuf, dqkv, batch, heads, ntok, hd, scale,
-                                              reinterpret_cast<hipStream_t>(stream)),
+                                              g_attn_variant, reinterpret_cast<hipStream_t>(stream)),
                     "vitk_attention_backward");
 }
 

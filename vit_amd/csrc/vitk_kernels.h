@@ -72,7 +72,7 @@ hipError_t launch_attention(const void* q, const void* k, const void* v, void* o
 int attention_bwd_max_tokens();
 hipError_t launch_attention_backward(const void* q, const void* k, const void* v, const void* o, const void* d_o,
                                      const float* lse, float* dbuf, void* dqkv, int batch, int heads, int ntok, int hd,
-                                     float scale, hipStream_t s);
+                                     float scale, int variant, hipStream_t s);
 hipError_t launch_gemm_f32(const float* A, const float* W, const float* bias, const float* resid, float* out, int M,
                            int N, int K, int epilogue, hipStream_t s);
 hipError_t launch_qkv_f32(const float* A, const float* W, const float* bias, float* qkv, int batch, int ntok,

@@ -51,50 +51,104 @@ __device__ __forceinline__ void attn_bwd_owner_block(const char* r1, const char*
     const int tsub = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
     const bool ragged = (ntok & 31) != 0;
     auto swz = [](int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); };
+    // ---- per-lane LDS offsets inside a resident block of 32 rows (4 KiB); the swizzle of a row depends on its bits
+    // 1..3 only, so none of them changes from block to block and a block costs one add per address
+    uint32_t off_row[KS];                  // the lane's row r, chunk 2 ks + hh: the ds_read_b128 of the S / dP products
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) off_row[ks] = (uint32_t)(r * RB + (((ks * 2 + hh) ^ swz(r)) << 4));
+    uint32_t off_tr[2][DB][2];             // transposed reads of the output products: k-step st, column block d, rows ka / ka + 8
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        const int ka = 16 * st + 4 * hh + tq, kb = ka + 8;
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+            const int chunk = d * 4 + tsub * 2 + (tp >> 1);
+            off_tr[st][d][0] = (uint32_t)(ka * RB + ((chunk ^ swz(ka)) << 4) + (tp & 1) * 8);
+            off_tr[st][d][1] = (uint32_t)(kb * RB + ((chunk ^ swz(kb)) << 4) + (tp & 1) * 8);
+        }
+    }
+    // MODE 0, last block of a ragged token count: bit i set if accumulator element i is a real key
+    uint32_t last_valid = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if ((blocks - 1) * 32 + 8 * (i >> 2) + 4 * hh + (i & 3) < ntok) last_valid |= 1u << i;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         f32x16 out1[DB], out2[DB];
 #pragma unroll
-        for (int d = 0; d < DB; ++d)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                out1[d][i] = 0.f;
-                out2[d][i] = 0.f;
-            }
+        for (int d = 0; d < DB; ++d) {
+            out1[d] = zero16;
+            out2[d] = zero16;
+        }
+        const f32x2 c2 = {c, c}, nl2 = {-Lc, -Lc}, nd2 = {-Dc, -Dc};
 
+        // the resident block's fragments for the S / dP products are requested one block ahead: the reads of block
+        // rb + 1 go out as soon as the MFMAs of block rb have taken their operands and land under the softmax arithmetic
+        bf16x8 a1[KS], a2[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            a1[ks] = *reinterpret_cast<const bf16x8*>(r1 + off_row[ks]);
+            a2[ks] = *reinterpret_cast<const bf16x8*>(r2 + off_row[ks]);
+        }
         for (int rb = 0; rb < blocks; ++rb) {
-            f32x16 s, dp;
+            const char* b1 = r1 + rb * 32 * RB;
+            const char* b2 = r2 + rb * 32 * RB;
+            // the first MFMA of each chain takes a literal zero as its C operand: no registers to clear
+            f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0], t1[0], zero16, 0, 0, 0);
+            f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[0], t2[0], zero16, 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                s[i] = 0.f;
-                dp[i] = 0.f;
+            for (int ks = 1; ks < KS; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ks], t1[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ks], t2[ks], dp, 0, 0, 0);
             }
-            const int row = rb * 32 + r;
-            const int sw = swz(row);
+            {
+                // (past the last block this reads the first again: in bounds, never used)
+                const int nb = rb + 1 < blocks ? (rb + 1) * 32 * RB : 0;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(r1 + row * RB + (((ks * 2 + hh) ^ sw) << 4));
-                const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(r2 + row * RB + (((ks * 2 + hh) ^ sw) << 4));
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, t1[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, t2[ks], dp, 0, 0, 0);
+                for (int ks = 0; ks < KS; ++ks) {
+                    a1[ks] = *reinterpret_cast<const bf16x8*>(r1 + nb + off_row[ks]);
+                    a2[ks] = *reinterpret_cast<const bf16x8*>(r2 + nb + off_row[ks]);
+                }
             }
-            // element i of a lane: resident row rb*32 + 8 (i >> 2) + 4 hh + (i & 3), owner row = the lane's
+            // the transposed fragments of the output products of this block, requested before the arithmetic as well
+            bf16x4 v0[2][DB], v1[2][DB], w0[2][DB], w1[2][DB];
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int d = 0; d < DB; ++d) {
+                    v0[st][d] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_b*)(b1 + off_tr[st][d][0]));
+                    v1[st][d] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_b*)(b1 + off_tr[st][d][1]));
+                    if constexpr (MODE == 1) {
+                        w0[st][d] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_b*)(b2 + off_tr[st][d][0]));
+                        w1[st][d] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_b*)(b2 + off_tr[st][d][1]));
+                    }
+                }
+            // element i of a lane: resident row rb*32 + 8 (i >> 2) + 4 hh + (i & 3), owner row = the lane's.
+            // Two elements per instruction (packed f32): p = exp2(s c - L), dS = p (dP - D); the factor `scale` of
+            // dQ and dK is applied once to the finished sums.
             f32x16 pr;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                f32x4 l4, d4;
+                f32x2 nl[2] = {nl2, nl2}, nd[2] = {nd2, nd2};
                 if constexpr (MODE == 1) {
-                    l4 = *reinterpret_cast<const f32x4*>(l_lds + rb * 32 + 8 * g + 4 * hh);
-                    d4 = *reinterpret_cast<const f32x4*>(d_lds + rb * 32 + 8 * g + 4 * hh);
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(l_lds + rb * 32 + 8 * g + 4 * hh);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(d_lds + rb * 32 + 8 * g + 4 * hh);
+                    nl[0] = f32x2{-l4[0], -l4[1]}; nl[1] = f32x2{-l4[2], -l4[3]};
+                    nd[0] = f32x2{-d4[0], -d4[1]}; nd[1] = f32x2{-d4[2], -d4[3]};
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int i = 4 * g + j;
-                    const float lc = MODE == 1 ? l4[j] : Lc;
-                    const float dc = MODE == 1 ? d4[j] : Dc;
-                    float p = __builtin_amdgcn_exp2f(fmaf(s[i], c, -lc));
-                    if (MODE == 0 && ragged && rb == blocks - 1 && rb * 32 + 8 * g + 4 * hh + j >= ntok) p = 0.f;
-                    pr[i] = p;
-                    s[i] = p * (dp[i] - dc) * scale;          // dS (scaled): s is reused
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int i = 4 * g + 2 * h2;
+                    const f32x2 e = f32x2{s[i], s[i + 1]} * c2 + nl[h2];
+                    const f32x2 p = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+                    const f32x2 ds = p * (f32x2{dp[i], dp[i + 1]} + nd[h2]);
+                    pr[i] = p[0]; pr[i + 1] = p[1];
+                    s[i] = ds[0]; s[i + 1] = ds[1];            // dS: s is reused
                 }
+            }
+            if (MODE == 0 && ragged && rb == blocks - 1) {      // keys past the last token: probability 0
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (!((last_valid >> i) & 1)) { pr[i] = 0.f; s[i] = 0.f; }
             }
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
@@ -104,25 +158,19 @@ __device__ __forceinline__ void attn_bwd_owner_block(const char* r1, const char*
                 u32x4 pk = {pack_bf16(pr[8 * st + 0], pr[8 * st + 1]), pack_bf16(pr[8 * st + 2], pr[8 * st + 3]),
                             pack_bf16(pr[8 * st + 4], pr[8 * st + 5]), pack_bf16(pr[8 * st + 6], pr[8 * st + 7])};
                 const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
-                const int ka = rb * 32 + 16 * st + 4 * hh + tq, kb = ka + 8;
 #pragma unroll
                 for (int d = 0; d < DB; ++d) {
-                    const int chunk = d * 4 + tsub * 2 + (tp >> 1);
-                    const int oa = ka * RB + ((chunk ^ swz(ka)) << 4) + (tp & 1) * 8;
-                    const int ob = kb * RB + ((chunk ^ swz(kb)) << 4) + (tp & 1) * 8;
-                    const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_b*)(r1 + oa));
-                    const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_b*)(r1 + ob));
-                    const bf16x8 af = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const bf16x8 af = __builtin_shufflevector(v0[st][d], v1[st][d], 0, 1, 2, 3, 4, 5, 6, 7);
                     out1[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, dsf, out1[d], 0, 0, 0);
                     if constexpr (MODE == 1) {
-                        const bf16x4 w0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_b*)(r2 + oa));
-                        const bf16x4 w1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_b*)(r2 + ob));
-                        const bf16x8 bf = __builtin_shufflevector(w0, w1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        const bf16x8 bf = __builtin_shufflevector(w0[st][d], w1[st][d], 0, 1, 2, 3, 4, 5, 6, 7);
                         out2[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, pf, out2[d], 0, 0, 0);
                     }
                 }
             }
         }
+#pragma unroll
+        for (int d = 0; d < DB; ++d) out1[d] = out1[d] * scale;   // dQ = scale dS K, dK = scale dS^T Q
 
         // ---- store: lane holds owner row orow, columns d = 32 blk + 8 g + 4 hh + (0..3)
         if (orow < ntok) {

@@ -218,7 +218,8 @@ def test_gpu_weight_gradient_gemm(R, M, N):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,H,N", [(2, 3, 197), (1, 2, 32), (1, 2, 33), (2, 2, 64), (1, 4, 257), (1, 1, 576), (3, 12, 197)])
+@pytest.mark.parametrize("B,H,N", [(2, 3, 197), (1, 2, 32), (1, 2, 33), (2, 2, 64), (1, 4, 257), (1, 1, 576), (3, 12, 197), (1, 2, 577),
+                                   (2, 1, 608)])
 def test_gpu_attention_backward_kernel(B, H, N):
     """vitk_attention_lse + vitk_attention_backward against torch autograd of softmax(q k^T s) v in fp64 on the
     same bf16 q, k, v and output gradient."""

@@ -274,7 +274,7 @@ def _attention_torch(q, k, v, scale):
 class AttentionFn(torch.autograd.Function):
     """ctx [B, N, H*hd] = softmax(q k^T scale) v, heads concatenated (models/transformer.py:43-46).
 
-    bf16, head_dim 64, N <= 576: the forward also keeps each row's log-sum-exp and the backward is the HIP
+    bf16, head_dim 64, N <= 608: the forward also keeps each row's log-sum-exp and the backward is the HIP
     kernel pair of attention_bwd.hip.  Otherwise the gradients come from recomputing with torch."""
 
     @staticmethod

@@ -378,7 +378,7 @@ static hipError_t attn_bwd_fused_launch(const void* q, const void* k, const void
     return hipGetLastError();
 }
 
-int attention_bwd_max_tokens() { return 576; }               // two resident [ntok, 64] bf16 matrices + L, D within 160 KiB
+int attention_bwd_max_tokens() { return 608; }               // two resident [ntok, 64] bf16 matrices + L, D within 160 KiB (155,648 + 4,864 B)
 
 template <int NW>
 static hipError_t attn_bwd_launch(const void* q, const void* k, const void* v, const void* o, const void* d_o,

@@ -392,7 +392,7 @@ def attention_lse(qkv, ctx, scale):
 
 
 def attention_backward_supported(N, hd):
-    return hd == 64 and N <= 576
+    return hd == 64 and N <= 608
 
 
 def attention_backward(qkv, ctx, dctx, lse, scale):

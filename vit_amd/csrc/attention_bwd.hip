@@ -7,7 +7,10 @@
 //   dP = dO V^T,  D = rowsum(dO * O),  dS = P * (dP - D)
 //   dQ = scale dS K,   dK = scale dS^T Q,   dV = P^T dO
 //
-// One kernel template, run twice per layer, one workgroup per (image, head) each time:
+// Two passes over a head, one workgroup per (image, head).  Up to 288 tokens both run in one kernel from one LDS image
+// of Q, K, V and dO (attention_bwd_fused: every matrix fetched once, D handed over through LDS); above, as two
+// launches of one kernel template that keeps two of the four matrices resident and reads the others' rows from global
+// memory (attention_bwd), with D in a caller's buffer:
 //   MODE 0 (dQ):     K and V resident in LDS; a wave owns 32 query rows (Q, dO fragments in registers), walks
 //                    the keys in blocks of 32:  S^T = K Q^T,  dP^T = V dO^T  (key on the MFMA row, query on
 //                    the lane, so L and D are per-lane scalars),  dQ^T += K^T dS^T.  Also computes D for its
@@ -237,8 +240,6 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd(const bf16_t* __restric
     }
 
     const int r = lane & 31, hh = lane >> 5;
-    const int tsub = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
-    const bool ragged = (ntok & 31) != 0;
     __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
     __syncthreads();
 

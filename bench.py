@@ -80,8 +80,17 @@ class KernelTimer:
         return sum(a.elapsed_time(b) for a, b in self.pairs) / max(len(self.pairs), 1)
 
 
-def cpu_baseline(arch, img_size, sd_cpu, batch):
-    """The CPU oracle (a port of the reference's forward) on this host's cores: warm-up + 3 runs."""
+def host_threads():
+    """The CPU threads this job may use: the scheduler affinity, capped by OMP_NUM_THREADS where the box sets
+    one (a GPU box reports the whole machine in os.cpu_count() but grants the job a share of it)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    omp = os.environ.get("OMP_NUM_THREADS", "")
+    if omp.isdigit() and int(omp) > 0:
+        n = min(n, int(omp))
+    return max(n, 1)
+
+
+def _time_oracle(arch, img_size, sd_cpu, batch):
     from oracle import vit_oracle as vo
     cfg = synth.ARCHS[arch]
     x = synth.synth_images(batch, img_size, seed=1)
@@ -92,47 +101,118 @@ def cpu_baseline(arch, img_size, sd_cpu, batch):
         vo.forward(sd_cpu, x, cfg)
         ts.append(time.perf_counter() - t0)
     ts.sort()
-    # cores = the threads torch actually ran on (the box grants this job a CPU share smaller than the machine
-    # and sets OMP_NUM_THREADS to it); host_cpus = what the machine reports
-    return {"value": round(batch / ts[1], 3), "unit": "images/s", "cores": torch.get_num_threads(),
+    return round(batch / ts[1], 3)
+
+
+def cpu_baseline(arch, img_size, sd_cpu, batch):
+    """The CPU oracle (a port of the reference's forward) on every host core this job may use: the benchmarked
+    model (warm-up + median of 3) and, beside it, ViT-S/16 224 fp32 batch 8, the reference's own CPU-runnable
+    configuration (BASELINE configs[0])."""
+    threads = host_threads()
+    torch.set_num_threads(threads)
+    main = _time_oracle(arch, img_size, sd_cpu, batch)
+    samples = [{"workload": f"{arch} {img_size}px fp32 forward, batch {batch}", "value": main, "unit": "images/s"}]
+    if (arch, img_size) != ("s16", 224):
+        sd_s = synth.synth_state_dict(synth.ARCHS["s16"], 224, seed=0)
+        samples.append({"workload": "s16 224px fp32 forward, batch 8 (BASELINE configs[0])",
+                        "value": _time_oracle("s16", 224, sd_s, 8), "unit": "images/s"})
+    # cores = the threads torch ran on (set explicitly above); host_cpus = what the machine reports
+    return {"value": main, "unit": "images/s", "cores": torch.get_num_threads(),
             "host_cpus": os.cpu_count(), "kind": "port",
-            "sample": f"{arch} {img_size}px fp32 forward, batch {batch}, median of 3 after warm-up"}
+            "sample": f"{arch} {img_size}px fp32 forward, batch {batch}, median of 3 after warm-up, "
+                      f"torch.set_num_threads({threads})",
+            "samples": samples}
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, timeout_s=600.0):
     """`python bench.py --gpus N` as ONE command: this parent starts N fresh child processes (one per GPU,
     the reference's process model: run.py:121-124, utils.py:95-96) with the torch.distributed environment
-    set, forwards rank 0's JSON line and returns non-zero if any rank fails.  The parent never touches a
-    GPU (no torch.cuda call happens before this point), and nothing is exec'ed."""
+    set, forwards rank 0's JSON line and returns non-zero if any rank fails or the launch outlives
+    `timeout_s`.  The parent never touches a GPU (no torch.cuda call happens before this point), nothing is
+    exec'ed, and no child outlives the parent: every rank is polled, the first non-zero exit (or the
+    deadline) ends the others, and the first failing rank's last stderr lines are printed."""
+    import tempfile
+    import threading
+
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].stdout.read().decode()
-    rc = 0
-    deadline = time.time() + 600
-    for p in procs:
-        try:
-            p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            p.wait()
-        rc = rc or p.returncode
-    for line in out0.splitlines():          # the JSON line to stdout, library chatter (gloo / RCCL banners) to stderr
-        print(line, file=sys.stdout if line.startswith("{") else sys.stderr, flush=True)
-    if rc != 0:
-        print(f"bench.py: a rank exited with status {rc}", file=sys.stderr)
-    return 1 if rc != 0 else 0
+    procs, errs = [], []
+    out0 = []
+    first_bad = None                       # (rank, status) of the first rank seen to fail
+    timed_out = False
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            errs.append(tempfile.TemporaryFile())
+            procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + argv, env=env,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=errs[r]))
+        # rank 0's stdout is drained by a thread, so that neither a full pipe nor a silent rank 0 blocks the poll
+        reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+        reader.start()
+        deadline = time.time() + timeout_s
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad and first_bad is None:
+                first_bad = bad[0]
+            if first_bad is not None or all(c is not None for c in codes):
+                break
+            if time.time() > deadline:
+                timed_out = True
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:                    # whoever is still running goes now: SIGTERM, then SIGKILL
+            if p.poll() is None:
+                p.terminate()
+        t_kill = time.time() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_kill - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    reader.join(timeout=5.0)
+    text = out0[0].decode(errors="replace") if out0 else ""
+    ok = first_bad is None and not timed_out
+    for line in text.splitlines():          # the JSON line to stdout, library chatter (gloo / RCCL banners) to stderr
+        is_json = line.startswith("{")
+        if is_json and not ok:
+            continue                        # no throughput claim from a launch that failed
+        print(line, file=sys.stdout if is_json else sys.stderr, flush=True)
+
+    def tail(r, lines=15):
+        errs[r].seek(0)
+        return "\n".join(errs[r].read().decode(errors="replace").splitlines()[-lines:])
+
+    if timed_out:
+        alive = [r for r, p in enumerate(procs) if p.returncode not in (0,)]
+        print(f"bench.py: launch exceeded {timeout_s:.0f} s; ranks ended by the parent: {alive}", file=sys.stderr)
+        for r in alive[:2]:
+            print(f"--- rank {r} stderr (tail)\n{tail(r)}", file=sys.stderr)
+    elif first_bad is not None:
+        r, c = first_bad
+        print(f"bench.py: rank {r} exited first with status {c}; the other ranks were ended\n"
+              f"--- rank {r} stderr (tail)\n{tail(r)}", file=sys.stderr)
+    else:
+        for r in range(n):                  # a clean launch still passes on what the ranks wrote to stderr
+            t = tail(r, 5)
+            if t:
+                print(t, file=sys.stderr)
+    for f in errs:
+        f.close()
+    return 0 if ok else 1
 
 
 def rehearse(a):
     """Launcher / barrier / max-over-ranks / JSON plumbing with NO GPU work (CPU-only test boxes): the step is
     a fixed host-side matmul.  The line it prints is labelled as a rehearsal and carries no throughput claim."""
+    if a.rehearse_hang_rank == int(os.environ.get("RANK", "0")):
+        time.sleep(3600)                    # a rank that never reaches the rendezvous (launcher tests)
+    if a.rehearse_die_rank == int(os.environ.get("RANK", "0")):
+        raise SystemExit(3)                 # a rank that dies before the rendezvous (launcher tests)
     rank, world, _ = vdist.init_from_env(backend="gloo")
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
@@ -170,10 +250,14 @@ def main():
                          "(forward, CrossEntropyLoss, backward, clip_grad_norm_ 1.0, AdamW; main.py:207-223 of the reference)")
     ap.add_argument("--rehearse", action="store_true",
                     help="exercise the multi-process launch and the timing reduction on CPU (gloo), no GPU work")
+    ap.add_argument("--launch-timeout", type=float, default=600.0,
+                    help="seconds after which the self-launching parent (--gpus N without WORLD_SIZE) ends every rank")
+    ap.add_argument("--rehearse-hang-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--rehearse-die-rank", type=int, default=-1, help=argparse.SUPPRESS)
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(launch_ranks(a.gpus, sys.argv[1:]))
+        raise SystemExit(launch_ranks(a.gpus, sys.argv[1:], a.launch_timeout))
     if a.rehearse:
         return rehearse(a)
 
@@ -217,7 +301,7 @@ def main():
         # as in main.py:125-126
         model.train()
         net = model
-        if world > 1:       # over RCCL in the real launch; over gloo when rehearsing several ranks on one GPU
+        if torch.distributed.is_initialized():   # over RCCL in the real launch (also a lone rank with the group forced on); over gloo when rehearsing several ranks on one GPU
             net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True)
         opt = torch.optim.AdamW(model.parameters(), 1e-3, weight_decay=0.03, fused=True)
         crit = torch.nn.CrossEntropyLoss()

@@ -41,7 +41,8 @@ int vitk_version(void);
 /* Message for the last non-zero return on the calling thread ("" if none). */
 const char* vitk_last_error(void);
 
-/* Test and measurement hook (state of the CALLING THREAD, default 0 = production kernels): choose an
+/* Test and measurement hook (one setting per PROCESS, default 0 = production kernels; it also reaches kernels
+ * launched from other threads, e.g. torch's autograd workers; not meant to be changed while launches are being issued): choose an
  * alternative implementation of the tiled GEMM and of attention.
  * gemm_variant, low 4 bits: 0 (and 4) = default (two-group phased kernel where K/64 is even and A is a
  *   plain matrix, else the one-group pipelined kernel), 1 = basic kernel with LDS-DMA staging, 2 = force
@@ -64,6 +65,12 @@ const char* vitk_last_error(void);
  *   bit 2 = K/V of head 0 for every head, bit 3 = no key loop, bit 4 = no output stores.
  * Results are identical across variants up to fp32 summation order. */
 void vitk_set_debug_variant(int gemm_variant, int attention_variant);
+
+/* Measurement hook (one setting per process): plan the persistent kernels (tiled GEMMs, attention, weight-gradient
+ * GEMM) for `cus` compute units instead of all of them; 0 restores the default.  Results do not depend on it.  Used to
+ * measure what a kernel gains per CU when part of the chip is idle (tools/exp_half_chip.sh) and to run micro-batches
+ * side by side on separate streams (tools/two_stream.py). */
+void vitk_set_cu_limit(int cus);
 
 /* y[r, :] = LayerNorm(x[r, :]) * gamma + beta over D columns, fp32 statistics.
  * x: f32, row r at x + r*x_row_stride; y: bf16 or f32 (out_dtype), row stride y_row_stride

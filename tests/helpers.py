@@ -26,11 +26,13 @@ def golden_inputs(meta):
     return cfg, sd, x
 
 
-def build_model(arch, img_size, sd, device):
+def build_model(arch, img_size, sd, device, precision="bf16"):
     """A vit_amd model holding `sd`, built on the meta device to skip the random init."""
     import vit_amd
     with torch.device("meta"):
         m = getattr(vit_amd, arch)(img_size=img_size)
     m = m.to_empty(device=device)
     m.load_state_dict(sd, strict=True)
+    if precision != "bf16":
+        m.set_precision(precision)
     return m.eval()

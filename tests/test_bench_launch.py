@@ -4,6 +4,7 @@ import json
 import os
 import subprocess
 import sys
+import time
 
 import pytest
 
@@ -33,10 +34,37 @@ def test_gpus_1_stays_a_single_process():
 
 
 def test_failed_rank_gives_non_zero_exit():
-    # without the rehearsal switch and without a GPU every rank stops before any timing: the parent must report it
+    # without the rehearsal switch every rank whose LOCAL_RANK has no GPU stops before any timing (all of them on a
+    # CPU box, rank 1 on a one-GPU box, where rank 0 would otherwise sit in the rendezvous): the parent must end
+    # the survivors and report the failure, within seconds
+    t0 = time.time()
     r = _run("--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline")
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "exited first with status" in r.stderr
+    assert time.time() - t0 < 120
+
+
+def test_rank_that_never_arrives_is_ended_at_the_deadline():
+    # rank 0 sleeps instead of joining the rendezvous: its stdout stays silent and open.  The parent's deadline
+    # covers rank 0 as well; it ends every child and returns non-zero shortly after the deadline.
+    t0 = time.time()
+    r = _run("--gpus", "2", "--steps", "1", "--warmup", "0", "--rehearse", "--rehearse-hang-rank", "0",
+             "--launch-timeout", "20")
+    took = time.time() - t0
+    assert r.returncode != 0
+    assert "launch exceeded 20 s" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert took < 90, took
+
+
+def test_rank_that_dies_ends_a_waiting_rank_zero():
+    # rank 1 never arrives because it is dead: rank 0 waits in the gloo rendezvous until the parent ends it
+    t0 = time.time()
+    r = _run("--gpus", "2", "--steps", "1", "--warmup", "0", "--rehearse", "--rehearse-die-rank", "1")
+    assert r.returncode != 0
+    assert "rank 1 exited first with status 3" in r.stderr
+    assert time.time() - t0 < 90
 
 
 
@@ -50,3 +78,16 @@ def test_rccl_group_initialises_and_reduces_on_the_gpu_with_one_rank():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 1 and out["value"] > 0
+
+
+@pytest.mark.gpu
+def test_training_step_under_ddp_over_rccl_on_the_gpu_with_one_rank():
+    """`--mode train` through DistributedDataParallel on the RCCL backend (main.py:125-126 of the reference): a lone
+    rank with the group forced on, so that DDP's bucket all-reduce runs over RCCL on real hardware."""
+    r = _run("--gpus", "1", "--mode", "train", "--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline",
+             env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29534",
+                  "VIT_AMD_FORCE_GROUP": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and "train" in out["metric"]
+    assert "RCCL" in out["config"]["parallelism"]

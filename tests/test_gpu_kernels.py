@@ -292,3 +292,61 @@ def test_gemm_tile_plans_at_full_size(M, N, K):
     assert torch.allclose(outs[0][0], resid + acc, rtol=1e-4, atol=2e-4 * max(K / 768, 1.0) ** 0.5)
     assert torch.allclose(outs[0][1].float(), F.gelu(acc), rtol=2 ** -7, atol=2e-3)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def _plan_is_mixed(M, N, K):
+    import ctypes
+    out = (ctypes.c_int * 10)()
+    assert lib.load().vitk_gemm_plan(M, N, K, 0, out) == 0
+    return out[4] == 1
+
+
+def test_qkv_projection_under_the_two_height_plan():
+    """A projection narrow enough for the plain tile order (3 n-tiles) with at least one tile per CU takes the
+    two-height plan, whose last panel of an XCD overhangs the XCD's row range: the head-major scatter epilogue must
+    honour the row limit.  Against torch, and bit for bit against the equal-tile plan (debug order bit 13)."""
+    B, N, H, hd = 139, 197, 4, 64
+    D = H * hd
+    assert _plan_is_mixed(B * N, 3 * D, D)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    a = torch.randn(B * N, D, generator=g, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(3 * D, D, generator=g, device=DEV) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(3 * D, generator=g, device=DEV) * 0.1
+    outs = []
+    for variant in (0, 0x20000):
+        lib.load().vitk_set_debug_variant(variant, 0)
+        qkv = torch.full((3, B, H, N, hd), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ops.qkv_proj(a, w, bias, qkv, B, N, H, hd)
+        outs.append(qkv)
+    want = (a.float() @ w.float().t() + bias).reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    assert torch.allclose(outs[0].float(), want, rtol=2 ** -7, atol=2e-3)
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_patch_matrix_embedding_under_the_two_height_plan():
+    """Patch 14 through the explicit patch matrix at a batch that gives every CU a tile (3 n-tiles, K = 640): the
+    patch epilogue (row -> token 1 + patch, position embedding added) under the two-height plan, against the
+    convolution and bit for bit against the equal-tile plan."""
+    B, S, P, D = 107, 224, 14, 768
+    n = (S // P) ** 2
+    k0 = 3 * P * P
+    kpad = (k0 + 63) // 64 * 64
+    assert _plan_is_mixed(B * n, D, kpad)
+    g = torch.Generator(device=DEV).manual_seed(12)
+    img = torch.randn(B, 3, S, S, generator=g, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(D, 3, P, P, generator=g, device=DEV) * 0.03).to(torch.bfloat16)
+    bias, cls = torch.randn(D, generator=g, device=DEV) * 0.1, torch.randn(D, generator=g, device=DEV)
+    pos = torch.randn(n + 1, D, generator=g, device=DEV) * 0.1
+    wp = torch.zeros(D, kpad, dtype=torch.bfloat16, device=DEV)
+    wp[:, :k0] = w.reshape(D, -1)
+    outs = []
+    for variant in (0, 0x20000):
+        lib.load().vitk_set_debug_variant(variant, 0)
+        out = torch.full((B, n + 1, D), float("nan"), device=DEV)
+        cols = torch.empty(B * n, kpad, dtype=torch.bfloat16, device=DEV)
+        ops.patch_embed_cols(img, wp, bias, cls, pos, out, cols, P)
+        outs.append(out)
+    conv = F.conv2d(img.float(), w.float(), bias, stride=P).flatten(2).transpose(1, 2)
+    want = torch.cat([cls.expand(B, 1, D), conv], dim=1) + pos
+    assert torch.allclose(outs[0], want, rtol=1e-4, atol=3e-4)
+    assert torch.equal(outs[0], outs[1])

@@ -31,10 +31,41 @@ def test_logits_match_reference(name):
     assert err <= TOL_BF16
     assert (y.argmax(-1) == g["top1"]).all()
     assert np.array_equal(y, y16)
-    # intermediates: embedding is a single bf16 GEMM (K=768) + fp32 adds
-    ws = next(iter(m._ws.values()))
-    xfin = ws.x.float().cpu().numpy()
-    assert xfin.shape[0] == meta["batch"]
+
+
+# Per-stage bounds for the bf16 path against the reference's own intermediates (max-abs; the values are of size
+# 2-4).  The oracle restated with bf16 rounding at the kernels' rounding points sits at 4.2-5.8e-3 / 7.1-9.4e-3 /
+# 1.9-2.4e-2 on these sets (embedding: one bf16 GEMM over K = 768 on N(0,1) pixels; after block 0: four more GEMMs
+# and the attention; encoded: twelve to twenty-four blocks and a LayerNorm that divides by a row deviation < 1).
+STAGE_TOL_BF16 = {"embed": 8e-3, "block0": 1.4e-2, "encoded": 3.2e-2}
+STAGE_TOL_FP32 = {"embed": 2e-5, "block0": 2e-5, "encoded": 1e-4}
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("name", ["b16_224_ref", "b16_224_pert", "b16_384_ref", "l16_224_ref", "s16_224_ref"])
+def test_stages_match_reference_intermediates(name, precision):
+    """The HIP path's own intermediates against what forward hooks on the reference's embedding (after cls / pos,
+    models/vision_transformer.py:47-50), first block and encoder captured: a logit-level pass cannot hide
+    compensating errors in the embedding or in block 0."""
+    meta, g = load_golden(name)
+    cfg, sd, x = golden_inputs(meta)
+    m = build_model(meta["arch"], meta["img_size"], sd, DEV, precision=precision)
+    seen = {}
+    m.stage_hook = lambda stage, t: seen.__setitem__(stage, t.detach().float().cpu().numpy().copy())
+    with torch.no_grad():
+        m(x.to(DEV))
+    m.stage_hook = None
+    B = meta["batch"]
+    got = {"embed": seen["embed"].reshape(B, -1, cfg["hidden_size"])[:, :5, :32],
+           "block0": seen["block0"].reshape(B, -1, cfg["hidden_size"])[:, -1, :],
+           "encoded": seen["encoded"]}
+    want = {"embed": g["embed_slice"], "block0": g["block0_last"], "encoded": g["encoded"]}
+    tol = STAGE_TOL_BF16 if precision == "bf16" else STAGE_TOL_FP32
+    errs = {k: float(np.abs(got[k] - want[k]).max()) for k in got}
+    print(f"{name} {precision}: " + ", ".join(f"{k} {v:.3e}" for k, v in errs.items()))
+    for k in got:
+        assert got[k].shape == want[k].shape
+        assert errs[k] <= tol[k], (k, errs[k])
 
 
 def test_h14_patch_14_head_dim_80():

@@ -206,7 +206,10 @@ __global__ __launch_bounds__(256) void gemm_f32_rows(const F32GemmArgs p) {
 template <int EPI, bool GATHER>
 static hipError_t launch_f32(const F32GemmArgs& a, hipStream_t s) {
     if constexpr (!GATHER && (EPI == F32_BIAS || EPI == F32_TANH)) {
-        if (a.M <= 1024 && a.K % 4 == 0 && (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 &&
+        // every 16-row block streams the whole of W once with no reuse in LDS: only while that stays small (the
+        // head at batches up to 1024: 64 blocks x 1000 x 768 words); anything heavier takes the tiled kernel
+        const long long w_words = (long long)((a.M + 15) / 16) * a.N * a.K;
+        if (a.M <= 1024 && w_words <= (64LL << 20) && a.K % 4 == 0 && (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 &&
             (reinterpret_cast<uintptr_t>(a.W) & 15) == 0) {
             dim3 grid((a.N + 127) / 128, (a.M + 15) / 16);
             hipLaunchKernelGGL((gemm_f32_rows<EPI>), grid, dim3(256), 0, s, a);

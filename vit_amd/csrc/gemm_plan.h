@@ -1,5 +1,7 @@
 // Tile plan shared by the persistent GEMM kernels: tile height, tile order, per-XCD chunks.
 #pragma once
+#include <atomic>
+
 #include "gemm_common.h"
 
 namespace vitk {
@@ -134,6 +136,9 @@ inline PipePlan make_plan(const GemmArgs& a, int cus, bool allow_mixed = false) 
     return pl;
 }
 
+// Measurement hook (vitk_set_cu_limit): size the persistent grids and tile plans for this many CUs (0 = all).
+extern std::atomic<int> g_cu_limit;
+
 inline int num_cus() {
     static int cus = 0;
     if (cus == 0) {
@@ -143,7 +148,8 @@ inline int num_cus() {
             cus = prop.multiProcessorCount;
         if (cus <= 0) cus = 256;
     }
-    return cus;
+    const int lim = g_cu_limit.load(std::memory_order_relaxed);
+    return lim > 0 && lim < cus ? lim : cus;
 }
 
 }  // namespace vitk

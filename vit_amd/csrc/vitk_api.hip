@@ -2,6 +2,7 @@
 // reporting.  Declarations and the reference call sites each entry point
 // replaces are in include/vitk.h.
 #include <stdarg.h>
+#include <atomic>
 #include <stdio.h>
 
 #include "../../include/vitk.h"
@@ -10,11 +11,18 @@
 
 using namespace vitk;
 
+namespace vitk {
+std::atomic<int> g_cu_limit{0};
+}
+
 namespace {
 
 thread_local char g_err[256] = "";
-thread_local int g_gemm_variant = 0;      // test hook (vitk_set_debug_variant): per calling thread, default 0
-thread_local int g_attn_variant = 0;
+// Test hook (vitk_set_debug_variant), one setting per process: torch runs autograd backward on its own worker
+// threads, and a per-thread setting made on the main thread would never reach the kernels launched from there.
+std::atomic<int> g_gemm_variant_a{0}, g_attn_variant_a{0};
+#define g_gemm_variant (g_gemm_variant_a.load(std::memory_order_relaxed))
+#define g_attn_variant (g_attn_variant_a.load(std::memory_order_relaxed))
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -62,14 +70,16 @@ int dense(const char* name, const void* A, const void* W, const float* bias, con
 
 extern "C" {
 
-int vitk_version(void) { return 6; }
+int vitk_version(void) { return 7; }
 
 const char* vitk_last_error(void) { return g_err; }
 
 void vitk_set_debug_variant(int gemm_variant, int attention_variant) {
-    g_gemm_variant = gemm_variant;
-    g_attn_variant = attention_variant;
+    g_gemm_variant_a.store(gemm_variant, std::memory_order_relaxed);
+    g_attn_variant_a.store(attention_variant, std::memory_order_relaxed);
 }
+
+void vitk_set_cu_limit(int cus) { vitk::g_cu_limit.store(cus > 0 ? cus : 0, std::memory_order_relaxed); }
 
 int vitk_layernorm(const float* x, int64_t x_row_stride, const float* gamma, const float* beta, void* y,
                    int64_t y_row_stride, int rows, int D, float eps, int out_dtype, void* stream) {

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VITK_LIB") or os.path.join(_HERE, "libvitk.so")
 
 VITK_F32, VITK_BF16 = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int
@@ -51,7 +51,7 @@ SIGNATURES = {
 }
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_TANH = 0, 1, 2, 3      # vitk_gemm_f32 epilogues (include/vitk.h)
 ACT_GELU, ACT_TANH = 0, 1                                    # vitk_gemm_grad_act
-EXPORTS = sorted(list(SIGNATURES) + ["vitk_version", "vitk_last_error", "vitk_set_debug_variant",
+EXPORTS = sorted(list(SIGNATURES) + ["vitk_version", "vitk_last_error", "vitk_set_debug_variant", "vitk_set_cu_limit",
                                     "vitk_gemm_tn_workspace", "vitk_gemm_tn_colsum_workspace"])
 
 _lib = None
@@ -77,6 +77,8 @@ def load():
     lib.vitk_last_error.argtypes = []
     lib.vitk_set_debug_variant.restype = None
     lib.vitk_set_debug_variant.argtypes = [_i, _i]
+    lib.vitk_set_cu_limit.restype = None
+    lib.vitk_set_cu_limit.argtypes = [_i]
     for fn in (lib.vitk_gemm_tn_workspace, lib.vitk_gemm_tn_colsum_workspace):
         fn.restype = _i64
         fn.argtypes = [_i, _i, _i]
@@ -87,6 +89,9 @@ def load():
     v = lib.vitk_version()
     if v != ABI_VERSION:
         raise VitkError(f"libvitk ABI version {v}, expected {ABI_VERSION}: rebuild with `python -m vit_amd.build --force`")
+    lim = os.environ.get("VITK_CU_LIMIT", "")       # measurement runs (tools/): plan for part of the chip
+    if lim.isdigit():
+        lib.vitk_set_cu_limit(int(lim))
     _lib = lib
     return lib
 

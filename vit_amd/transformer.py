@@ -118,11 +118,17 @@ class Encoder(nn.Module):
             for i in range(num_layers)])
         self.norm = norm(hidden_size)
 
-    def fused(self, ws, w):
+    def fused(self, ws, w, stage_hook=None):
         """All blocks, then the final LayerNorm on the cls row only: LayerNorm is per token
-        and the reference keeps just token 0 afterwards (models/transformer.py:98-99)."""
+        and the reference keeps just token 0 afterwards (models/transformer.py:98-99).
+        `stage_hook(name, tensor)`, if given, sees the residual stream after block 0 ("block0") and the
+        normalised cls rows ("encoded"): what a forward hook on the reference's modules would see."""
         for i, blk in enumerate(self.blocks):
             blk.fused(ws, w, f"b{i}.")
+            if i == 0 and stage_hook is not None:
+                stage_hook("block0", ws.x)
         B, N, D = ws.x.shape
         ops.layernorm(ws.x, w["norm.w"], w["norm.b"], _eps_of(self.norm), ws.cls_n, rows=B, x_row_stride=N * D)
+        if stage_hook is not None:
+            stage_hook("encoded", ws.cls_n)
         return ws.cls_n

@@ -58,6 +58,10 @@ class VisionTransformer(nn.Module):
         # not part of state_dict: kernel-ready weights and activation buffers
         self._cache = WeightCache(self, fp32=self.precision == "fp32")
         self._ws = {}
+        # Test hook: callable(name, tensor) that sees the inference path's intermediate buffers in place ("embed":
+        # tokens after cls / pos, "block0": residual stream after the first block, "encoded": normalised cls rows),
+        # the points a forward hook on the reference's embedding, blocks[0] and encoder would observe.
+        self.stage_hook = None
 
     def set_precision(self, precision):
         if precision not in ("bf16", "fp32"):
@@ -130,7 +134,9 @@ class VisionTransformer(nn.Module):
             elif x.dtype not in (torch.float32, torch.bfloat16):
                 raise VitkError(f"unsupported image dtype {x.dtype}")
             ops.patch_embed_f32(x.float().contiguous(), w["embed.w"], w["embed.b"], w["cls"], w["pos"], ws.x, P)
-            feat = self.encoder.fused(ws, w)
+            if self.stage_hook is not None:
+                self.stage_hook("embed", ws.x)
+            feat = self.encoder.fused(ws, w, self.stage_hook)
             if "pre.w" in w:
                 ops.gemm_f32(feat, w["pre.w"], w["pre.b"], ws.pre, EPI_TANH)
                 feat = ws.pre
@@ -153,7 +159,9 @@ class VisionTransformer(nn.Module):
         else:
             cols = ws.patch_cols(B * (N - 1), w["embed.w"].shape[1], x.device)
             ops.patch_embed_cols(img16, w["embed.w"], w["embed.b"], w["cls"], w["pos"], ws.x, cols, P)
-        feat = self.encoder.fused(ws, w)             # f32 [B, D]: from here on f32 kernels in both modes
+        if self.stage_hook is not None:
+            self.stage_hook("embed", ws.x)
+        feat = self.encoder.fused(ws, w, self.stage_hook)    # f32 [B, D]: from here on f32 kernels in both modes
         if "pre.w" in w:
             ops.gemm_f32(feat, w["pre.w"], w["pre.b"], ws.pre, EPI_TANH)
             feat = ws.pre

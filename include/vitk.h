@@ -262,6 +262,35 @@ int vitk_colsum_bf16(const void* G, float* out, float* partials, int partial_row
  * host logic of this library, exposed so that it can be tested without a GPU. */
 int vitk_gemm_plan(int M, int N, int K, int cus, int* plan);
 
+/* ---- LayerNorm folded into the GEMMs either side of it (inference path) ----------------------------
+ * Encoder1DBlock computes x = x + out_proj(..); y = norm2(x); h = gelu(fc1(y)) and x = x + fc2(h); y = norm1(x);
+ * qkv = in_proj(y) (models/transformer.py:66-76, :40-48, :20-26).  With these four entry points the LayerNorm
+ * between a residual GEMM and the projection that follows it needs no pass of its own over x:
+ *   LN(x) W^T + b = rstd (x W'^T - mean s) + c,  W' = W * gamma (per input column), s[n] = sum_k W'[n][k],
+ *   c[n] = b[n] + sum_k beta[k] W[n][k].
+ * The residual GEMM's epilogue writes the statistics and a bf16 copy of the new rows, the projection runs on that
+ * copy with W' and applies the two row factors in its epilogue.  Shapes: M >= 128, N a multiple of 256, K of 128,
+ * every tensor below 4 GiB; anything else returns VITK_ERR_UNSUPPORTED and the caller keeps vitk_layernorm. */
+
+/* vitk_gemm_bias_residual that also writes out_bf16 [M,N] = bf16(out) and stats f32 [M, N/64, 2]: per row and
+ * 64-column strip the sum and the sum of squares of the new row's f32 values.  out may alias resid. */
+int vitk_gemm_bias_residual_ln(const void* A, const void* W, const float* bias, const float* resid, float* out,
+                               void* out_bf16, float* stats, int M, int N, int K, void* stream);
+
+/* ab f32 [rows, 2] = (rstd, -mean * rstd) of every row from the strip statistics over D columns (strips added in
+ * index order; biased variance, eps inside the root as nn.LayerNorm has it, models/transformer.py:56,60). */
+int vitk_ln_finalize(const float* stats, float* ab, int rows, int D, float eps, void* stream);
+
+/* out bf16 [M,N] = gelu(ab[m][0] * (A @ Wg^T)[m][n] + ab[m][1] * colsum[n] + c[n]): norm2 + fc1 + GELU
+ * (models/transformer.py:73-74, :21-22) on A = bf16(x), Wg = bf16(W * gamma), colsum[n] = sum_k Wg[n][k]. */
+int vitk_gemm_ln_bias_gelu(const void* A, const void* Wg, const float* ab, const float* colsum, const float* c, void* out,
+                           int M, int N, int K, void* stream);
+
+/* The same value for the fused q/k/v projection, scattered head-major like vitk_qkv_proj: norm1 + in_proj
+ * (models/transformer.py:68-69, :42). */
+int vitk_qkv_proj_ln(const void* A, const void* Wg, const float* ab, const float* colsum, const float* c, void* qkv,
+                     int batch, int ntok, int heads, int hd, void* stream);
+
 /* ---- for callers that cannot allocate ------------------------------------------------------------- */
 
 /* Optional set-up for the current device: resolves the library's built-in scratch (used by

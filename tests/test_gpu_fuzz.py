@@ -191,12 +191,16 @@ def test_fuzz_whole_model_against_the_oracle(case):
     m = m.to(DEV).eval()
     with torch.no_grad():
         got = m(x.to(DEV)).float().cpu()
+        m.fold_layernorm = False                 # one vitk_layernorm launch per LayerNorm, as the training path has it
+        got_sep = m(x.to(DEV)).float().cpu()
+        m.fold_layernorm = True
         m.set_precision("fp32")
         got32 = m(x.to(DEV)).float().cpu()
     assert (got32 - want).abs().max().item() <= 1e-4
-    # the training path (autograd Functions) computes the same logits as the inference path, in both modes, and
-    # hands a finite gradient to every parameter
-    for prec, ref in (("fp32", got32), ("bf16", got)):
+    # the training path (autograd Functions) computes the same logits as the inference path with separate LayerNorm
+    # launches, in both modes, and hands a finite gradient to every parameter (the default inference path folds the
+    # LayerNorms into the GEMMs around them: other bf16 roundings, held to the oracle below)
+    for prec, ref in (("fp32", got32), ("bf16", got_sep)):
         m.set_precision(prec)
         m.train()
         y = m(x.to(DEV))
@@ -207,7 +211,9 @@ def test_fuzz_whole_model_against_the_oracle(case):
         m.eval()
     # bf16 mode: the 1e-2 bar belongs to the reference's configurations (tests/test_gpu_model.py); perturbed weights
     # at D = 1280 reach 1.1e-2, an indexing mistake anywhere gives 1e-1 and more
-    assert (got - want).abs().max().item() <= 2e-2
+    e_fold, e_sep = (got - want).abs().max().item(), (got_sep - want).abs().max().item()
+    print(f"bf16 vs oracle: folded {e_fold:.2e}, separate {e_sep:.2e}")
+    assert e_fold <= 2e-2 and e_sep <= 2e-2
 
 
 @pytest.mark.parametrize("g,G,D", [(2, 3, 8), (14, 24, 768), (24, 14, 768), (7, 7, 64), (3, 37, 100), (16, 5, 257), (1, 4, 16), (12, 13, 1280)])

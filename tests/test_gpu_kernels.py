@@ -350,3 +350,67 @@ def test_patch_matrix_embedding_under_the_two_height_plan():
     want = torch.cat([cls.expand(B, 1, D), conv], dim=1) + pos
     assert torch.allclose(outs[0], want, rtol=1e-4, atol=3e-4)
     assert torch.equal(outs[0], outs[1])
+
+
+# ----------------------------------------------------------------------------- LayerNorm folded into the GEMMs around it
+@pytest.mark.parametrize("M,D,N2,K0", [(50432, 768, 3072, 768), (2000, 768, 2304, 3072), (788, 1024, 4096, 1024),
+                                       (131, 256, 768, 256), (50432 + 77, 768, 2304, 768), (5000, 1280, 5120, 1280)])
+def test_layernorm_folded_into_the_gemms_either_side(M, D, N2, K0):
+    """x = x + a W0^T + b0 with the statistics and the bf16 copy from the residual epilogue, then
+    gelu(LN(x) W1^T + b1) and the q/k/v projection of LN(x) from that copy with gamma-scaled weights
+    (models/transformer.py:68-76).  The producer against torch (f32 product of the bf16 operands), the row factors
+    against f64 statistics of the produced rows, the consumers against the oracle's LayerNorm in f32 followed by an
+    f32 product: the error left is the bf16 rounding of the operands, held to the size the unfolded kernels
+    (vitk_layernorm + vitk_gemm_bias_gelu) show on the same inputs."""
+    g = torch.Generator(device=DEV).manual_seed(M + D + N2)
+    a = torch.randn(M, K0, generator=g, device=DEV).to(torch.bfloat16)
+    w0 = (torch.randn(D, K0, generator=g, device=DEV) * 0.03).to(torch.bfloat16)
+    b0 = torch.randn(D, generator=g, device=DEV) * 0.1
+    x0 = torch.randn(M, D, generator=g, device=DEV) * 1.5 + 0.4 * torch.randn(M, 1, generator=g, device=DEV)
+    gamma = 1 + 0.2 * torch.randn(D, generator=g, device=DEV)
+    beta = 0.1 * torch.randn(D, generator=g, device=DEV)
+    w1 = torch.randn(N2, D, generator=g, device=DEV) * 0.04
+    b1 = torch.randn(N2, generator=g, device=DEV) * 0.1
+    eps = 1e-6
+
+    x = x0.clone()
+    x16 = torch.full((M, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    stats = torch.full((M, D // 64, 2), float("nan"), device=DEV)
+    ab = torch.empty(M, 2, device=DEV)
+    ops.gemm_bias_residual_ln(a, w0, b0, x, x, x16, stats)
+    ops.ln_finalize(stats, ab, D, eps)
+    plain = x0.clone()
+    ops.gemm_bias_residual(a, w0, b0, plain, plain)
+    assert torch.equal(x, plain)                                   # the same residual update, bit for bit
+    assert torch.equal(x16, x.to(torch.bfloat16))
+    xd = x.double()
+    mean, var = xd.mean(1), xd.var(1, unbiased=False)
+    rstd = (var + eps).rsqrt()
+    assert torch.allclose(ab[:, 0].double(), rstd, rtol=2e-5, atol=0)
+    assert torch.allclose(ab[:, 1].double(), -mean * rstd, rtol=2e-5, atol=2e-6)
+
+    wg = (w1 * gamma[None, :]).to(torch.bfloat16)
+    s = wg.float().sum(1)
+    c = b1 + w1 @ beta
+    y = vo.layernorm(x.cpu(), gamma.cpu(), beta.cpu(), eps).to(DEV)
+    want = y.double() @ w1.double().t() + b1.double()
+    h = torch.empty(M, N2, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_ln_bias_gelu(x16, wg, ab, s, c, h)
+    # the unfolded kernels on the same inputs
+    y16 = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    ops.layernorm(x, gamma, beta, eps, y16)
+    h_plain = torch.empty(M, N2, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_bias_gelu(y16, w1.to(torch.bfloat16), b1, h_plain)
+    ref = F.gelu(want).float()
+    e_fold, e_plain = (h.float() - ref).abs(), (h_plain.float() - ref).abs()
+    print(f"M={M} D={D}: folded max {e_fold.max():.2e} mean {e_fold.mean():.2e}; unfolded max {e_plain.max():.2e} mean {e_plain.mean():.2e}")
+    assert e_fold.max() <= 4e-2 and e_fold.mean() <= 1.5 * e_plain.mean() + 1e-4
+
+    if N2 % 3 == 0 and (N2 // 3) == D and D % 64 == 0:             # the q/k/v projection of the same rows
+        H, hd = D // 64, 64
+        Bq = 1
+        qkv = torch.full((3, Bq, H, M, hd), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ops.qkv_proj_ln(x16, wg, ab, s, c, qkv, Bq, M, H, hd)
+        wantq = want.float().reshape(Bq, M, 3, H, hd).permute(2, 0, 3, 1, 4)
+        eq = (qkv.float() - wantq).abs()
+        assert eq.max() <= 4e-2 and eq.mean() <= 1.5 * e_plain.mean() + 1e-3

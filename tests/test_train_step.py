@@ -124,8 +124,11 @@ def test_gpu_gradients_match_reference_vectors(precision, logit_tol, rel_tol, co
     total = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
     assert abs(float(total) - float(g["total_norm"])) <= rel_tol * float(g["total_norm"])
     print(f"{precision}: logits {err:.3e}, worst relative gradient error {worst:.3e}")
-    with torch.no_grad():                                                 # the inference path gives the same logits
+    with torch.no_grad():     # the inference path with one launch per LayerNorm gives the same logits, bit for bit;
+        m.fold_layernorm = False      # the default one (LayerNorms folded into the GEMMs around them) within the bar
         assert torch.equal(m(x.cuda()), logits.detach())
+        m.fold_layernorm = True
+        assert (m(x.cuda()) - logits.detach()).abs().max().item() <= logit_tol
 
 
 @pytest.mark.gpu

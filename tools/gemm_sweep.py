@@ -37,6 +37,17 @@ def main():
         if epi == "resid":
             out = torch.zeros(M, N, dtype=torch.float32, device=dev)
             run = lambda: ops.gemm_bias_residual(A, W, b, out, out)   # noqa: E731
+        elif epi == "residln":      # the residual epilogue that also writes the bf16 copy and the LayerNorm statistics
+            out = torch.zeros(M, N, dtype=torch.float32, device=dev)
+            out16 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            stats = torch.empty(M, N // 64, 2, device=dev)
+            run = lambda: ops.gemm_bias_residual_ln(A, W, b, out, out, out16, stats)   # noqa: E731
+        elif epi == "lngelu":       # the GELU epilogue with the LayerNorm row factors (here 1 and 0: same values as gelu)
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            ab = torch.zeros(M, 2, device=dev)
+            ab[:, 0] = 1.0
+            cs = torch.zeros(N, device=dev)
+            run = lambda: ops.gemm_ln_bias_gelu(A, W, ab, cs, b, out)   # noqa: E731
         elif epi == "gelu":
             out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
             run = lambda: ops.gemm_bias_gelu(A, W, b, out)            # noqa: E731

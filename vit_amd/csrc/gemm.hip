@@ -262,6 +262,13 @@ hipError_t launch_gemm_tiled(const GemmArgs& a, int epilogue, bool gather, int v
                 return hipErrorInvalidValue;
             if (variant != 5 && gemm_pp_supports(a, false)) return launch_gemm_pp(a, epilogue, s);
             return launch_gemm_pipe(a, epilogue, false, s);
+        case EPI_RESID_LN_F32:
+        case EPI_LN_GELU_BF16:
+        case EPI_LN_QKV_BF16:              // the two-group persistent kernel only
+            if ((size_t)(a.M + 256) * a.N * 4 >= (1ull << 32) || (size_t)a.M * a.lda * 2 >= (1ull << 32) ||
+                (size_t)a.N * a.K * 2 >= (1ull << 32) || !gemm_pp_supports(a, false))
+                return hipErrorInvalidValue;
+            return launch_gemm_pp(a, epilogue, s);
         case EPI_BIAS_RESID_F32: return launch_variant<EPI_BIAS_RESID_F32, false>(a, variant, s);
         case EPI_QKV_BF16: return launch_variant<EPI_QKV_BF16, false>(a, variant, s);
         case EPI_BIAS_F32: return launch_variant<EPI_BIAS_F32, false>(a, variant, s);

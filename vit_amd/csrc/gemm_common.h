@@ -28,6 +28,15 @@ __device__ __forceinline__ void advance_row(int& b, int& t, int step, int per) {
     while (t >= per) { t -= per; ++b; }
 }
 
+// sum over the 16 lanes of a DPP row (lanes 16 i .. 16 i + 15): four rotate-and-add steps, every lane gets the total
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xF, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, false));
+    return v;
+}
+
 // Epilogue of one wave's sub-tile: acc[nt][mt][j] = C[m = mw + 16 mt + fr][n = nw + 16 nt + 4 fq + j]
 // for mt < my_mt (fr = lane & 15, fq = lane >> 4).  Accumulators (+bias, +GELU/tanh) go through the
 // wave-private LDS window `win` and are read back as 16-byte row pieces, so every global store
@@ -40,8 +49,11 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
                                               int nw, int my_mt, int row_limit, int lane) {
     const int fr = lane & 15, fq = lane >> 4;
     constexpr bool AUXMUL = (EPI == EPI_MUL_DGELU_BF16 || EPI == EPI_MUL_DTANH_BF16);   // out = bf16(acc) * f'(aux)
+    constexpr bool LNIN = (EPI == EPI_LN_GELU_BF16 || EPI == EPI_LN_QKV_BF16);      // LayerNorm applied to the accumulators
+    constexpr bool QKV = (EPI == EPI_QKV_BF16 || EPI == EPI_LN_QKV_BF16);
+    constexpr bool LNOUT = EPI == EPI_RESID_LN_F32;                                 // row statistics + bf16 copy of the new rows
     constexpr bool OUT_BF16 = (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_BIAS_TANH_BF16 ||
-                               EPI == EPI_QKV_BF16 || EPI == EPI_BIAS_GELU_DUAL_BF16 || AUXMUL);
+                               QKV || EPI == EPI_BIAS_GELU_DUAL_BF16 || AUXMUL || LNIN);
     constexpr bool DUAL = EPI == EPI_BIAS_GELU_DUAL_BF16;       // two trips through the window: pre-activation, then GELU
     if constexpr (OUT_BF16) {
         // window = 32 rows x 128 B.  8-byte piece (row r, chunk c, half h) lives at
@@ -53,10 +65,25 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
             b4[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (p.bias) b4[nt] = *reinterpret_cast<const f32x4*>(p.bias + nw + nt * 16 + fq * 4);
         }
+        // LNIN: value = rstd[m] acc + (-mean[m] rstd[m]) s[n] + c[n]: the column sums s beside the bias (here c), and
+        // the two row factors of this lane's eight rows
+        f32x4 s4[LNIN ? 4 : 1];
+        f32x2 ab8[LNIN ? 8 : 1];
+        if constexpr (LNIN) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) s4[nt] = *reinterpret_cast<const f32x4*>(p.ln_s + nw + nt * 16 + fq * 4);
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                if (MASKED && mt >= my_mt) break;
+                int row = mw + mt * 16 + fr;
+                row = row < p.M ? row : p.M - 1;
+                ab8[mt] = *reinterpret_cast<const f32x2*>(p.ln_ab + 2 * (size_t)row);
+            }
+        }
         const int rc = lane >> 3, cc = lane & 7;     // read-back role: row within 8, 16-byte chunk
         uint32_t col_off;                            // element offset contributed by the column
         int rb0 = 0, rt0 = 0;                        // QKV: (image, token) of row mw
-        if constexpr (EPI == EPI_QKV_BF16) {
+        if constexpr (QKV) {
             // column n of the fused projection = which*D + h*hd + e  (reshape(B,N,3,H,hd), transformer.py:42).
             // The divisions run on wave-uniform values (scalar unit); per lane only when the wave's 64
             // columns straddle a head boundary (head_dim not a multiple of 64).
@@ -102,7 +129,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
             if (MASKED && pass * 2 >= my_mt) break;
 #pragma unroll
             for (int rep = 0; rep < (DUAL ? 2 : 1); ++rep) {
-            const bool gelu_now = EPI == EPI_BIAS_GELU_BF16 || (DUAL && rep == 1);
+            const bool gelu_now = EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_LN_GELU_BF16 || (DUAL && rep == 1);
             char* dst = reinterpret_cast<char*>((DUAL && rep == 0) ? p.out2 : p.out);
             u32x4 (&auxv)[4] = aux_all[AUX_UPFRONT ? pass : 0];
             if constexpr (AUXMUL && !AUX_UPFRONT) load_aux(auxv, pass);
@@ -113,7 +140,17 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
                     const f32x4 a = acc[nt][pass * 2 + m2];
-                    float v0 = a[0] + b4[nt][0], v1 = a[1] + b4[nt][1], v2 = a[2] + b4[nt][2], v3 = a[3] + b4[nt][3];
+                    float v0, v1, v2, v3;
+                    if constexpr (LNIN) {
+                        // on packed f32 arithmetic (v_pk_fma_f32): two instructions per pair of values
+                        const f32x2 ra = {ab8[pass * 2 + m2][0], ab8[pass * 2 + m2][0]};
+                        const f32x2 rb = {ab8[pass * 2 + m2][1], ab8[pass * 2 + m2][1]};
+                        const f32x2 lo = f32x2{a[0], a[1]} * ra + (rb * f32x2{s4[nt][0], s4[nt][1]} + f32x2{b4[nt][0], b4[nt][1]});
+                        const f32x2 hi = f32x2{a[2], a[3]} * ra + (rb * f32x2{s4[nt][2], s4[nt][3]} + f32x2{b4[nt][2], b4[nt][3]});
+                        v0 = lo[0]; v1 = lo[1]; v2 = hi[0]; v3 = hi[1];
+                    } else {
+                        v0 = a[0] + b4[nt][0]; v1 = a[1] + b4[nt][1]; v2 = a[2] + b4[nt][2]; v3 = a[3] + b4[nt][3];
+                    }
                     if (gelu_now) {
                         f32x2 g01 = {v0, v1}, g23 = {v2, v3};
                         gelu_erf_x4(g01, g23);
@@ -128,7 +165,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
                 }
             }
             int rb = rb0, rt = rt0;
-            if constexpr (EPI == EPI_QKV_BF16) advance_row(rb, rt, pass * 32 + rc, p.ntok);
+            if constexpr (QKV) advance_row(rb, rt, pass * 32 + rc, p.ntok);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = i * 8 + rc;
@@ -148,7 +185,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
                 }
                 const int lr = pass * 32 + r;                     // row inside the wave's sub-tile
                 uint32_t off;                                     // element offset (< 2^31: checked by the launcher)
-                if constexpr (EPI == EPI_QKV_BF16) {
+                if constexpr (QKV) {
                     off = ((uint32_t)rb * p.heads * p.ntok + rt) * p.hd + col_off;
                     advance_row(rb, rt, 8, p.ntok);
                 } else {
@@ -171,7 +208,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
         const int ncol = nw + cc * 4;
         f32x4 bias_rb = {0.f, 0.f, 0.f, 0.f};       // bias in read-back layout: added after the transpose
         if (p.bias) bias_rb = *reinterpret_cast<const f32x4*>(p.bias + ncol);
-        constexpr bool ADDEND = (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_PATCH_F32);
+        constexpr bool ADDEND = (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_PATCH_F32 || LNOUT);
         constexpr int QB = (EPI == EPI_PATCH_F32) ? 1 : 2;     // m-tiles per addend batch (register budget)
         // 32-bit byte offsets from the (uniform) tensor bases keep the address registers few; the
         // launcher guarantees that every tensor touched here is smaller than 4 GiB.
@@ -202,7 +239,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
                         orw[q][i] = (uint32_t)(rb * p.ntok + 1 + rt);
                         ad[q][i] = *reinterpret_cast<const f32x4*>(pos_b + ((uint32_t)(1 + rt) * p.N + ncol) * 4u);
                         advance_row(rb, rt, 4, p.npatch);
-                    } else if constexpr (EPI == EPI_BIAS_RESID_F32) {
+                    } else if constexpr (EPI == EPI_BIAS_RESID_F32 || LNOUT) {
                         ad[q][i] = *reinterpret_cast<const f32x4*>(resid_b + ((uint32_t)m * p.ldo + ncol) * 4u);
                     }
                 }
@@ -237,6 +274,21 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
                     const uint32_t orow_i = (EPI == EPI_PATCH_F32) ? orw[q][i] : (uint32_t)(mw + lr);
                     if (!MASKED || lr < row_limit)
                         *reinterpret_cast<f32x4*>(out_b + (orow_i * p.ldo + ncol) * 4u) = v;
+                    if constexpr (LNOUT) {
+                        // the new row's bf16 copy (the next GEMM's operand) and this strip's share of its LayerNorm
+                        // statistics: 16 lanes hold the row's 64 columns of this wave
+                        const f32x2 vlo = {v[0], v[1]}, vhi = {v[2], v[3]};      // packed f32: 5 instructions for both sums
+                        const f32x2 s2 = vlo + vhi, q2 = vhi * vhi + vlo * vlo;
+                        const float ps = row16_sum(s2[0] + s2[1]);
+                        const float pq = row16_sum(q2[0] + q2[1]);
+                        if (!MASKED || lr < row_limit) {
+                            const u32x2 pk = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                            *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(p.out2) + (orow_i * p.ldo + ncol) * 2u) = pk;
+                            if (cc == 0)     // 32-bit offsets: the launcher keeps every tensor below 4 GiB
+                                *reinterpret_cast<f32x2*>(reinterpret_cast<char*>(p.ln_stats) +
+                                                          (orow_i * (uint32_t)(p.N >> 6) + (uint32_t)(nw >> 6)) * 8u) = f32x2{ps, pq};
+                        }
+                    }
                 }
             }
             // a later batch goes into the registers this one has just released

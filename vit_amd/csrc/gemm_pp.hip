@@ -426,6 +426,9 @@ hipError_t launch_gemm_pp(const GemmArgs& a, int epilogue, hipStream_t s) {
         case EPI_BIAS_TANH_BF16: return launch_pp<EPI_BIAS_TANH_BF16>(a, s);
         case EPI_MUL_DGELU_BF16: return launch_pp<EPI_MUL_DGELU_BF16>(a, s);
         case EPI_MUL_DTANH_BF16: return launch_pp<EPI_MUL_DTANH_BF16>(a, s);
+        case EPI_RESID_LN_F32: return launch_pp<EPI_RESID_LN_F32>(a, s);
+        case EPI_LN_GELU_BF16: return launch_pp<EPI_LN_GELU_BF16>(a, s);
+        case EPI_LN_QKV_BF16: return launch_pp<EPI_LN_QKV_BF16>(a, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -90,6 +90,31 @@ hipError_t launch_layernorm(const float* x, int64_t x_row_stride, const float* g
     }
 }
 
+// Row factors of a LayerNorm folded into the GEMMs either side of it: the producing GEMM's epilogue left (sum, sum of
+// squares) per row and 64-column strip; this adds the strips in index order and writes (rstd, -mean * rstd) per row
+// (biased variance, eps inside the root: nn.LayerNorm, models/transformer.py:56,60).  One lane per row.
+__global__ __launch_bounds__(256) void ln_finalize_rows(const float* __restrict__ stats, float* __restrict__ ab, int rows,
+                                                        int strips, float inv_d, float eps) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    const f32x4* sp = reinterpret_cast<const f32x4*>(stats + (size_t)row * strips * 2);     // strips is even: 16-byte pieces
+    float s = 0.f, q = 0.f;
+    for (int i = 0; i < strips / 2; ++i) {
+        const f32x4 v = sp[i];
+        s += v[0]; q += v[1];
+        s += v[2]; q += v[3];
+    }
+    const float mean = s * inv_d;
+    const float var = fmaxf(q * inv_d - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    *reinterpret_cast<f32x2*>(ab + 2 * (size_t)row) = f32x2{rstd, -mean * rstd};
+}
+
+hipError_t launch_ln_finalize(const float* stats, float* ab, int rows, int D, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(ln_finalize_rows, dim3((rows + 255) / 256), dim3(256), 0, s, stats, ab, rows, D / 64, 1.0f / D, eps);
+    return hipGetLastError();
+}
+
 // x[b, 0, :] = cls_token + pos_embed[0]   (vision_transformer.py:48-50)
 __global__ void cls_pos_rows(const float* __restrict__ cls, const float* __restrict__ pos,
                              float* __restrict__ x, int batch, int ntok, int D) {

@@ -70,7 +70,7 @@ int dense(const char* name, const void* A, const void* W, const float* bias, con
 
 extern "C" {
 
-int vitk_version(void) { return 7; }
+int vitk_version(void) { return 8; }
 
 const char* vitk_last_error(void) { return g_err; }
 
@@ -202,6 +202,77 @@ int vitk_qkv_proj(const void* A, const void* W, const float* bias, void* qkv, in
     const int v = g_gemm_variant & 15;
     return launched(launch_gemm_tiled(a, EPI_QKV_BF16, false, v == 2 ? 0 : v, reinterpret_cast<hipStream_t>(stream)),
                     "vitk_qkv_proj");
+}
+
+// ---- LayerNorm folded into the GEMMs either side of it (inference path) ------------------------
+
+static bool ln_fold_shape_ok(int M, int N, int K) {
+    return M >= 128 && N % 256 == 0 && K % 128 == 0 && K >= 128;
+}
+
+int vitk_gemm_bias_residual_ln(const void* A, const void* W, const float* bias, const float* resid, float* out,
+                               void* out_bf16, float* stats, int M, int N, int K, void* stream) {
+    const char* name = "vitk_gemm_bias_residual_ln";
+    if (!A || !W || !resid || !out || !out_bf16 || !stats) return fail(VITK_ERR_INVALID, "%s: null pointer", name);
+    if (M <= 0 || N <= 0 || K <= 0) return fail(VITK_ERR_INVALID, "%s: non-positive size %dx%dx%d", name, M, N, K);
+    if (!aligned16(A) || !aligned16(W) || !aligned16(out) || !aligned16(resid) || !aligned16(out_bf16) || !aligned16(stats) ||
+        (bias && !aligned16(bias)))
+        return fail(VITK_ERR_INVALID, "%s: pointers must be 16-byte aligned", name);
+    if (!ln_fold_shape_ok(M, N, K))
+        return fail(VITK_ERR_UNSUPPORTED, "%s: M=%d N=%d K=%d (M >= 128, N a multiple of 256, K of 128)", name, M, N, K);
+    GemmArgs a = {};
+    a.A = A; a.W = W; a.bias = bias; a.out = out; a.resid = resid; a.out2 = out_bf16; a.ln_stats = stats;
+    a.M = M; a.N = N; a.K = K; a.lda = K; a.ldo = N;
+    a.order = g_gemm_variant >> 4;
+    hipError_t e = launch_gemm_tiled(a, EPI_RESID_LN_F32, false, 0, reinterpret_cast<hipStream_t>(stream));
+    if (e == hipErrorInvalidValue) return fail(VITK_ERR_UNSUPPORTED, "%s: a tensor of 4 GiB or more", name);
+    return launched(e, name);
+}
+
+int vitk_ln_finalize(const float* stats, float* ab, int rows, int D, float eps, void* stream) {
+    if (!stats || !ab) return fail(VITK_ERR_INVALID, "vitk_ln_finalize: null pointer");
+    if (rows <= 0 || D <= 0 || D % 128 != 0) return fail(VITK_ERR_INVALID, "vitk_ln_finalize: rows=%d D=%d (D a multiple of 128)", rows, D);
+    if (!aligned16(stats) || !aligned16(ab)) return fail(VITK_ERR_INVALID, "vitk_ln_finalize: pointers must be 16-byte aligned");
+    return launched(launch_ln_finalize(stats, ab, rows, D, eps, reinterpret_cast<hipStream_t>(stream)), "vitk_ln_finalize");
+}
+
+int vitk_gemm_ln_bias_gelu(const void* A, const void* Wg, const float* ab, const float* colsum, const float* c, void* out,
+                           int M, int N, int K, void* stream) {
+    const char* name = "vitk_gemm_ln_bias_gelu";
+    if (!A || !Wg || !ab || !colsum || !c || !out) return fail(VITK_ERR_INVALID, "%s: null pointer", name);
+    if (M <= 0 || N <= 0 || K <= 0) return fail(VITK_ERR_INVALID, "%s: non-positive size %dx%dx%d", name, M, N, K);
+    if (!aligned16(A) || !aligned16(Wg) || !aligned16(ab) || !aligned16(colsum) || !aligned16(c) || !aligned16(out))
+        return fail(VITK_ERR_INVALID, "%s: pointers must be 16-byte aligned", name);
+    if (!ln_fold_shape_ok(M, N, K))
+        return fail(VITK_ERR_UNSUPPORTED, "%s: M=%d N=%d K=%d (M >= 128, N a multiple of 256, K of 128)", name, M, N, K);
+    GemmArgs a = {};
+    a.A = A; a.W = Wg; a.bias = c; a.out = out; a.ln_ab = ab; a.ln_s = colsum;
+    a.M = M; a.N = N; a.K = K; a.lda = K; a.ldo = N;
+    a.order = g_gemm_variant >> 4;
+    hipError_t e = launch_gemm_tiled(a, EPI_LN_GELU_BF16, false, 0, reinterpret_cast<hipStream_t>(stream));
+    if (e == hipErrorInvalidValue) return fail(VITK_ERR_UNSUPPORTED, "%s: a tensor of 4 GiB or more", name);
+    return launched(e, name);
+}
+
+int vitk_qkv_proj_ln(const void* A, const void* Wg, const float* ab, const float* colsum, const float* c, void* qkv,
+                     int batch, int ntok, int heads, int hd, void* stream) {
+    const char* name = "vitk_qkv_proj_ln";
+    if (!A || !Wg || !ab || !colsum || !c || !qkv) return fail(VITK_ERR_INVALID, "%s: null pointer", name);
+    if (batch <= 0 || ntok <= 0 || heads <= 0 || hd <= 0) return fail(VITK_ERR_INVALID, "%s: non-positive size", name);
+    if (!aligned16(A) || !aligned16(Wg) || !aligned16(ab) || !aligned16(colsum) || !aligned16(c) || !aligned16(qkv))
+        return fail(VITK_ERR_INVALID, "%s: pointers must be 16-byte aligned", name);
+    const int D = heads * hd;
+    if (hd % 8 != 0) return fail(VITK_ERR_UNSUPPORTED, "%s: hd=%d not a multiple of 8", name, hd);
+    if (!ln_fold_shape_ok(batch * ntok, 3 * D, D))
+        return fail(VITK_ERR_UNSUPPORTED, "%s: rows=%d D=%d (rows >= 128, 3 D a multiple of 256, D of 128)", name, batch * ntok, D);
+    GemmArgs a = {};
+    a.A = A; a.W = Wg; a.bias = c; a.out = qkv; a.ln_ab = ab; a.ln_s = colsum;
+    a.M = batch * ntok; a.N = 3 * D; a.K = D; a.lda = D; a.ldo = 0;
+    a.ntok = ntok; a.heads = heads; a.hd = hd; a.batch = batch;
+    a.order = g_gemm_variant >> 4;
+    hipError_t e = launch_gemm_tiled(a, EPI_LN_QKV_BF16, false, 0, reinterpret_cast<hipStream_t>(stream));
+    if (e == hipErrorInvalidValue) return fail(VITK_ERR_UNSUPPORTED, "%s: a tensor of 4 GiB or more", name);
+    return launched(e, name);
 }
 
 static int attention_forward(const char* name, const void* q, const void* k, const void* v, void* ctx, float* lse,

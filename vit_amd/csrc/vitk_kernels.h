@@ -16,6 +16,13 @@ enum Epilogue {
     EPI_BIAS_GELU_DUAL_BF16 = 7,  // training: out = gelu(acc + bias) and out2 bf16 [M,N] = acc + bias (the pre-activation)
     EPI_MUL_DGELU_BF16 = 8,  // training: out bf16 [M,N] = bf16(acc) * gelu'(aux), aux bf16 [M,N] = the pre-activation
     EPI_MUL_DTANH_BF16 = 9,  // training: out bf16 [M,N] = bf16(acc) * (1 - aux^2), aux bf16 [M,N] = the tanh output
+    // LayerNorm folded into the GEMMs either side of it (inference).  Producer: the residual epilogue also writes
+    // out2 = bf16(out) and, per row and 64-column strip, (sum, sum of squares) of the new row to ln_stats.
+    // Consumers: A = bf16(x), W pre-multiplied by gamma; LN(x) W^T = rstd (x W'^T - mean s) + c with
+    // s[n] = sum_k W'[n][k], c[n] = bias[n] + sum_k beta[k] W[n][k] (passed as `bias`), per-row (rstd, -mean rstd) in ln_ab.
+    EPI_RESID_LN_F32 = 10,   // out f32 [M,N] = resid + acc + bias; out2 bf16 [M,N]; ln_stats f32 [M, N/64, 2]
+    EPI_LN_GELU_BF16 = 11,   // out bf16 [M,N] = gelu(ln_ab[m][0] acc + ln_ab[m][1] ln_s[n] + bias[n])
+    EPI_LN_QKV_BF16 = 12,    // the same value scattered head-major as EPI_QKV_BF16
 };
 
 // epilogues of the fp32-mode GEMM (f32path.hip)
@@ -30,6 +37,9 @@ struct GemmArgs {
     const float* resid;  // EPI_BIAS_RESID_F32 (may alias out)
     const float* pos;    // EPI_PATCH_F32: pos_embed [Ntok,N]
     const void* aux;     // EPI_MUL_*: bf16 [M,N] (row stride ldo), what the activation's derivative is taken of
+    float* ln_stats;     // EPI_RESID_LN_F32: f32 [M, N/64, 2]
+    const float* ln_ab;  // EPI_LN_*: f32 [M, 2] = (rstd, -mean * rstd) of every row of x
+    const float* ln_s;   // EPI_LN_*: f32 [N] column sums of the gamma-scaled bf16 weight
     int M, N, K;
     int lda, ldo;        // row strides in elements
     int ntok, heads, hd, batch;                 // EPI_QKV_BF16 / EPI_PATCH_F32
@@ -43,6 +53,7 @@ hipError_t launch_gemm_small(const GemmArgs& a, int epilogue, hipStream_t s);
 hipError_t launch_layernorm(const float* x, int64_t x_row_stride, const float* gamma, const float* beta,
                             void* y, int64_t y_row_stride, int rows, int D, float eps, bool out_bf16,
                             hipStream_t s);
+hipError_t launch_ln_finalize(const float* stats, float* ab, int rows, int D, float eps, hipStream_t s);
 hipError_t launch_cls_pos(const float* cls, const float* pos, float* x, int batch, int ntok, int D,
                           hipStream_t s);
 hipError_t launch_im2col(const void* img, void* cols, int batch, int img_h, int img_w, int patch, int kpad,

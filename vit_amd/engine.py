@@ -45,17 +45,39 @@ class WeightCache:
     def _signature(self):
         return tuple((p.data_ptr(), p._version, p.device) for p in self._model.parameters())
 
-    def get(self, train=False):
+    def get(self, train=False, fold=False):
         """Kernel-ready tensors; train=True adds what the backward GEMMs need (bf16 mode): `*.wt`, each GEMM
         weight transposed ([in, out]), so that the input gradient g W is the forward kernel's A W'^T with
-        W' = W^T."""
+        W' = W^T.  fold=True adds what the projections need that apply the preceding LayerNorm in their own
+        epilogue (bf16 mode, inference): see _add_folded."""
         key = self._signature()
         if key != self._key:
             self._rebuild()
             self._key = key
         if train and not self._fp32 and "train" not in self.t:
             self._add_transposed()
+        if fold and not self._fp32 and "fold" not in self.t:
+            self._add_folded()
         return self.t
+
+    def _add_folded(self):
+        """LN(x) W^T + b = rstd (x Wg^T - mean s) + c  with  Wg = W * gamma (per input column, rounded to bf16: the
+        operand the matrix pipe sees), s[n] = sum_k Wg[n, k] (of the ROUNDED values, so that the mean's share of
+        x Wg^T cancels exactly), c[n] = b[n] + sum_k beta[k] W[n, k] (f32).  For in_proj after norm1 and fc1 after
+        norm2 of every block (models/transformer.py:68-69,73-74)."""
+        t = self.t
+        for i, blk in enumerate(self._model.encoder.blocks):
+            p = f"b{i}."
+            for name, lin, norm in (("qkv", blk.attention.in_proj, "norm1"), ("fc1", blk.mlp.fc1, "norm2")):
+                w32 = lin.weight.detach().to(torch.float32)
+                gamma, beta = t[p + norm + ".w"], t[p + norm + ".b"]
+                wg = (w32 * gamma[None, :]).to(torch.bfloat16).contiguous()
+                t[p + name + ".wg"] = wg
+                t[p + name + ".s"] = wg.to(torch.float32).sum(dim=1).contiguous()
+                b = t[p + name + ".b"]
+                c = w32 @ beta
+                t[p + name + ".c"] = (c if b is None else c + b).contiguous()
+        t["fold"] = True
 
     def invalidate(self):
         """Drop the derived copies: call after changing parameters through `.data` (which `_version` does
@@ -124,6 +146,9 @@ class Workspace:
         self.cls_n = e(B, D, dtype=f32)          # the head runs in f32 in both modes
         self.pre = e(B, D, dtype=f32)
         self.logits = e(B, ncls, dtype=f32)
+        # LayerNorm folded into the GEMMs either side of it: strip statistics and per-row factors
+        self.ln_stats = None if fp32 else e(B * N, max(D // 64, 1), 2, dtype=f32)
+        self.ln_ab = None if fp32 else e(B * N, 2, dtype=f32)
         self.img16 = None
         self.cols = None
 

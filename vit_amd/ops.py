@@ -185,6 +185,76 @@ def gemm_bias_residual(a, w, bias, resid, out):
     return out
 
 
+def ln_fold_ok(rows, D, mlp):
+    """Shapes for which the LayerNorm between a residual GEMM and the following projection can be folded into the
+    two (vitk_gemm_bias_residual_ln / vitk_gemm_ln_bias_gelu / vitk_qkv_proj_ln): the two-group persistent GEMM's
+    shapes with every tensor below 4 GiB."""
+    return (rows >= 128 and D % 256 == 0 and mlp % 256 == 0 and D % 128 == 0 and mlp % 128 == 0
+            and (rows + 256) * max(3 * D, mlp) * 4 < (1 << 32))
+
+
+def gemm_bias_residual_ln(a, w, bias, resid, out, out16, stats):
+    """out f32 = resid + a @ w.T + bias (may be `resid` itself); out16 = bf16(out); stats f32 [M, N/64, 2] = per row
+    and 64-column strip (sum, sum of squares) of the new row."""
+    L = _lib.load()
+    _chk(a, torch.bfloat16, "A"); _chk(w, torch.bfloat16, "W"); _chk(bias, torch.float32, "bias")
+    _chk(resid, torch.float32, "resid"); _chk(out, torch.float32, "out"); _chk(out16, torch.bfloat16, "out16")
+    _chk(stats, torch.float32, "stats")
+    M, N, K = _dense_shapes(a, w, out, "gemm_bias_residual_ln")
+    if tuple(resid.shape) != (M, N) or tuple(out16.shape) != (M, N) or stats.numel() != M * (N // 64) * 2:
+        raise _lib.VitkError(f"gemm_bias_residual_ln: resid {tuple(resid.shape)} out16 {tuple(out16.shape)} "
+                             f"stats {tuple(stats.shape)} vs out [{M},{N}]")
+    with _span("gemm_bias_residual"):
+        _lib.check(L.vitk_gemm_bias_residual_ln(_ptr(a), _ptr(w), _ptr(bias), _ptr(resid), _ptr(out), _ptr(out16),
+                                                _ptr(stats), M, N, K, _stream()), L)
+    return out
+
+
+def ln_finalize(stats, ab, D, eps):
+    """ab f32 [rows, 2] = (rstd, -mean * rstd) per row from the strip statistics of a D-column LayerNorm."""
+    L = _lib.load()
+    _chk(stats, torch.float32, "stats"); _chk(ab, torch.float32, "ab")
+    rows = ab.shape[0]
+    if ab.numel() != rows * 2 or stats.numel() != rows * (D // 64) * 2:
+        raise _lib.VitkError(f"ln_finalize: stats {tuple(stats.shape)} ab {tuple(ab.shape)} D={D}")
+    with _span("ln_finalize"):
+        _lib.check(L.vitk_ln_finalize(_ptr(stats), _ptr(ab), rows, D, float(eps), _stream()), L)
+    return ab
+
+
+def gemm_ln_bias_gelu(a, wg, ab, colsum, c, out):
+    """out bf16 = gelu(LN(x) @ w.T + bias) from a = bf16(x), wg = bf16(w * gamma), the row factors ab and the
+    column vectors colsum[n] = sum_k wg[n, k], c[n] = bias[n] + sum_k beta[k] w[n, k]."""
+    L = _lib.load()
+    _chk(a, torch.bfloat16, "A"); _chk(wg, torch.bfloat16, "Wg"); _chk(out, torch.bfloat16, "out")
+    for n, t in (("ab", ab), ("colsum", colsum), ("c", c)):
+        _chk(t, torch.float32, n)
+    M, N, K = _dense_shapes(a, wg, out, "gemm_ln_bias_gelu")
+    if ab.numel() != 2 * M or colsum.numel() != N or c.numel() != N:
+        raise _lib.VitkError("gemm_ln_bias_gelu: ab / colsum / c sizes")
+    with _span("gemm_bias_gelu"):
+        _lib.check(L.vitk_gemm_ln_bias_gelu(_ptr(a), _ptr(wg), _ptr(ab), _ptr(colsum), _ptr(c), _ptr(out), M, N, K,
+                                            _stream()), L)
+    return out
+
+
+def qkv_proj_ln(a, wg, ab, colsum, c, qkv, batch, ntok, heads, hd):
+    """qkv_proj of LN(x) from a = bf16(x) [batch*ntok, D] (see gemm_ln_bias_gelu for the other operands)."""
+    L = _lib.load()
+    _chk(a, torch.bfloat16, "A"); _chk(wg, torch.bfloat16, "Wg"); _chk(qkv, torch.bfloat16, "qkv")
+    for n, t in (("ab", ab), ("colsum", colsum), ("c", c)):
+        _chk(t, torch.float32, n)
+    D = heads * hd
+    if tuple(a.shape) != (batch * ntok, D) or tuple(wg.shape) != (3 * D, D) or \
+            tuple(qkv.shape) != (3, batch, heads, ntok, hd) or ab.numel() != 2 * batch * ntok or \
+            colsum.numel() != 3 * D or c.numel() != 3 * D:
+        raise _lib.VitkError(f"qkv_proj_ln: shapes A{tuple(a.shape)} W{tuple(wg.shape)} qkv{tuple(qkv.shape)}")
+    with _span("qkv_proj"):
+        _lib.check(L.vitk_qkv_proj_ln(_ptr(a), _ptr(wg), _ptr(ab), _ptr(colsum), _ptr(c), _ptr(qkv), batch, ntok,
+                                      heads, hd, _stream()), L)
+    return qkv
+
+
 def qkv_proj(a, w, bias, qkv, batch, ntok, heads, hd):
     """a bf16 [batch*ntok, D]; qkv bf16 [3, batch, heads, ntok, hd]."""
     L = _lib.load()

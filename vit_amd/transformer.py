@@ -16,6 +16,8 @@ Data flow of one block (models/transformer.py:66-76), x = fp32 residual stream:
     x   = x + h W_2^T + b             -> fp32        vitk_gemm_bias_residual
 In the fp32 compute mode the same flow runs on f32 buffers through vitk_*_f32.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -117,16 +119,68 @@ class Encoder(nn.Module):
                            norm=norm, drop_prob=drop_probs[i])
             for i in range(num_layers)])
         self.norm = norm(hidden_size)
+        # which LayerNorms the folded path (fold_ok) takes out of the blocks: norm1 of blocks 1.. (statistics from
+        # the previous block's fc2) and norm2 (statistics from out_proj)
+        mode = os.environ.get("VIT_AMD_LN_FOLD_MODE", "both")
+        self.fold_norm1, self.fold_norm2 = mode in ("both", "ln1"), mode in ("both", "ln2")
+
+    def fold_ok(self, ws):
+        """Whether the LayerNorms between the blocks' GEMMs can be folded into them (bf16 mode, shapes of the
+        two-group GEMM kernel): every norm LayerNorm-like, and the library's shape rule."""
+        if ws.fp32 or not len(self.blocks):
+            return False
+        B, N, D = ws.x.shape
+        return ops.ln_fold_ok(B * N, D, self.blocks[0].mlp.fc1.out_features)
+
+    def _blocks_folded(self, ws, w, stage_hook):
+        """The blocks with every LayerNorm but the first folded into its neighbours: the residual GEMM before it
+        leaves bf16(x) in ws.y and the row statistics, the projection after it runs on bf16(x) with gamma-scaled
+        weights and applies rstd / mean in its epilogue (same values as y = LN(x); the bf16 rounding moves from y
+        to x and from W to W * gamma)."""
+        B, N, D = ws.x.shape
+        x2 = ws.x.view(B * N, D)
+        H = ws.qkv.shape[2]
+        hd = D // H
+        last = len(self.blocks) - 1
+        fold1, fold2 = self.fold_norm1, self.fold_norm2
+        normed = False                       # ws.y / ws.ln_ab hold bf16(x) and the row factors of the coming norm1
+        for i, blk in enumerate(self.blocks):
+            p = f"b{i}."
+            if normed:
+                ops.qkv_proj_ln(ws.y, w[p + "qkv.wg"], ws.ln_ab, w[p + "qkv.s"], w[p + "qkv.c"], ws.qkv, B, N, H, hd)
+            else:
+                ops.layernorm(x2, w[p + "norm1.w"], w[p + "norm1.b"], _eps_of(blk.norm1), ws.y)
+                ops.qkv_proj(ws.y, w[p + "qkv.w"], w[p + "qkv.b"], ws.qkv, B, N, H, hd)
+            ops.attention(ws.qkv, ws.ctx, blk.attention.scaling)
+            if fold2:
+                ops.gemm_bias_residual_ln(ws.ctx.view(B * N, D), w[p + "out.w"], w[p + "out.b"], x2, x2, ws.y, ws.ln_stats)
+                ops.ln_finalize(ws.ln_stats, ws.ln_ab, D, _eps_of(blk.norm2))
+                ops.gemm_ln_bias_gelu(ws.y, w[p + "fc1.wg"], ws.ln_ab, w[p + "fc1.s"], w[p + "fc1.c"], ws.h)
+            else:
+                ops.gemm_bias_residual(ws.ctx.view(B * N, D), w[p + "out.w"], w[p + "out.b"], x2, x2)
+                ops.layernorm(x2, w[p + "norm2.w"], w[p + "norm2.b"], _eps_of(blk.norm2), ws.y)
+                ops.gemm_bias_gelu(ws.y, w[p + "fc1.w"], w[p + "fc1.b"], ws.h)
+            normed = fold1 and i < last
+            if normed:
+                ops.gemm_bias_residual_ln(ws.h, w[p + "fc2.w"], w[p + "fc2.b"], x2, x2, ws.y, ws.ln_stats)
+                ops.ln_finalize(ws.ln_stats, ws.ln_ab, D, _eps_of(self.blocks[i + 1].norm1))
+            else:
+                ops.gemm_bias_residual(ws.h, w[p + "fc2.w"], w[p + "fc2.b"], x2, x2)
+            if i == 0 and stage_hook is not None:
+                stage_hook("block0", ws.x)
 
     def fused(self, ws, w, stage_hook=None):
         """All blocks, then the final LayerNorm on the cls row only: LayerNorm is per token
         and the reference keeps just token 0 afterwards (models/transformer.py:98-99).
         `stage_hook(name, tensor)`, if given, sees the residual stream after block 0 ("block0") and the
         normalised cls rows ("encoded"): what a forward hook on the reference's modules would see."""
-        for i, blk in enumerate(self.blocks):
-            blk.fused(ws, w, f"b{i}.")
-            if i == 0 and stage_hook is not None:
-                stage_hook("block0", ws.x)
+        if "fold" in w:
+            self._blocks_folded(ws, w, stage_hook)
+        else:
+            for i, blk in enumerate(self.blocks):
+                blk.fused(ws, w, f"b{i}.")
+                if i == 0 and stage_hook is not None:
+                    stage_hook("block0", ws.x)
         B, N, D = ws.x.shape
         ops.layernorm(ws.x, w["norm.w"], w["norm.b"], _eps_of(self.norm), ws.cls_n, rows=B, x_row_stride=N * D)
         if stage_hook is not None:

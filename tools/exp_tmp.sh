@@ -1,2 +1,1 @@
-python -u tools/gemm_sweep.py --epi=resid --rounds=3 --launches=100 50432 768 3072 50432 768 768 2>&1 | grep variant
-python -u tools/gemm_sweep.py --epi=residln --rounds=3 --launches=100 50432 768 3072 50432 768 768 2>&1 | grep variant
+timeout -k 10 200 python -u tools/attn_sweep.py --variant=0,0x800 --rounds=5 --launches=100 256 12 197 64 256 16 197 64 2>&1 | grep -v amdgpu.ids

@@ -29,12 +29,28 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
 
 constexpr float kMaskedScore = -1.0e30f;
+
+// f(integral_constant<int, I>) for I = First .. Last - 1, unrolled at compile time
+template <int First, int Last, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (First < Last) {
+        f(std::integral_constant<int, First>{});
+        static_for<First + 1, Last>(f);
+    }
+}
 // Timing probes (K/V of head 0 for every head, no key loop, no stores: wrong or no results) exist in
 // diagnostic builds only; elsewhere the kernel's `probe` argument is ignored and the checks fold away.
 #ifdef VITK_PROBES
 #define VITK_ATTN_PROBE(p) (p)
+// probe bit 3 (diagnostic builds): workgroup 0 writes cycle stamps of its first 12 heads over the start of the
+// output tensor, uint32 [head][wave][8]: 0 head start (before the wait for the staged K/V), 1 after the barrier,
+// 2 next head's LDS-DMA and query loads issued, 3..6 after each key step, 7 after normalising and storing
+#define VITK_ATTN_STAMP(slot)                                                                         \
+    if ((probe & 8) && blockIdx.x == 0 && it < 12 && lane == 0)                                        \
+        reinterpret_cast<uint32_t*>(O)[(it * NW + wave) * 8 + (slot)] = (uint32_t)clock64();
 #else
 #define VITK_ATTN_PROBE(p) 0
+#define VITK_ATTN_STAMP(slot)
 #endif
 
 // VTR = true : V row-major in LDS, transposed fragments via ds_read_b64_tr_b16.
@@ -55,8 +71,13 @@ constexpr float kMaskedScore = -1.0e30f;
 // blockIdx.x + gridDim.x, ... with two K/V buffers: the LDS-DMA of the next head (and the loads of its
 // queries) run under the current head's key loop, so the memory system never waits for a workgroup to
 // retire and the next one to be launched.  Needs two heads' K and V in LDS.
-template <int HD, int NW, bool VTR, bool STREAM, bool PD = false>
-__global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restrict__ Q,
+//
+// LW = true (PD only): one more wave, the last, does nothing but issue the LDS-DMA of the next head.  Issuing a
+// head's ~56 DMA instructions costs the waves that share them 2,000-3,300 cycles of a 15,000-cycle head at 197
+// tokens (each instruction waits for the address path, and nothing else of that wave runs meanwhile); the extra
+// wave sits on the SIMD that has only one q-tile of the seven, and the compute waves go straight to their keys.
+template <int HD, int NW, bool VTR, bool STREAM, bool PD = false, bool LW = false>
+__global__ __launch_bounds__((NW + (LW ? 1 : 0)) * 64) void attention_fwd(const bf16_t* __restrict__ Q,
                                                          const bf16_t* __restrict__ K,
                                                          const bf16_t* __restrict__ V,
                                                          bf16_t* __restrict__ O, int ntok, int heads,
@@ -65,6 +86,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
     static_assert(HD == 64 || ((HD == 96 || HD == 80) && VTR), "head_dim 64, or 80 / 96 with transposed LDS reads");
     static_assert(VTR || !STREAM, "streaming needs the transposed LDS reads");
     static_assert(!PD || (VTR && !STREAM), "the persistent variant stages whole heads by LDS-DMA");
+    static_assert(!LW || PD, "the loader wave belongs to the persistent variant");
     constexpr int KS = HD / 16;                  // k-steps of q k^T
     constexpr int DB = (HD + 31) / 32;           // 32-row blocks of O^T (the last one half used at head_dim 80:
                                                  // its upper V columns are copies of chunk 9, never stored)
@@ -74,6 +96,11 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
     constexpr int KC = 64;                       // keys per streamed chunk
     constexpr int CHUNK = 2 * KC * RB;           // bytes of one chunk buffer: K rows, then V rows
     constexpr bool OVL = PD || STREAM;           // LDS-DMA in flight during the key loop
+    // 32-key blocks per key step: what the registers hold besides O^T (two waves per SIMD: 256 registers)
+#ifndef VITK_ATTN_NBMAX
+#define VITK_ATTN_NBMAX 2
+#endif
+    constexpr int NBMAX = (PD && HD == 64 && NW + (LW ? 1 : 0) <= 8) ? VITK_ATTN_NBMAX : 2;
     constexpr bool MSUM = OVL || NW > 8;         // row sums on the matrix pipe (16 more registers: not where 4 waves share a SIMD)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -96,11 +123,11 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
     // applied to each lane's SOURCE chunk.  Rows past ntok re-read the last row (finite values: such keys
     // are masked out of the softmax, and their P is 0 in P.V); at head_dim 96 the slots whose chunk would
     // be 12..15 re-read chunk 11 and are never read back.
-    auto stage = [&](char* dst, int row0, int pieces, int head) {
+    auto stage = [&](char* dst, int row0, int pieces, int head, int first = -1, int stride = NW) {
         if (VITK_ATTN_PROBE(probe) & 1) head = 0;                            // timing probe: K/V from one head (cache-resident)
         const bf16_t* kg = K + (size_t)head * ntok * HD;
         const bf16_t* vg = V + (size_t)head * ntok * HD;
-        for (int pi = wave; pi < 2 * pieces; pi += NW) {     // wave-uniform
+        for (int pi = first < 0 ? wave : first; pi < 2 * pieces; pi += stride) {     // wave-uniform
             const bool is_v = pi >= pieces;
             const int lrow = (is_v ? pi - pieces : pi) * RPP + lane / CPR;
             const int slot = lane % CPR;
@@ -115,7 +142,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
     if constexpr (STREAM) {
         stage(smem, 0, KC / RPP, bh);
     } else if constexpr (VTR) {
-        stage(smem, 0, kpad / RPP, bh);
+        stage(smem, 0, kpad / RPP, bh, wave, NW + (LW ? 1 : 0));
     } else if constexpr (HD == 64) {
         char* kw = smem;
         char* vw = smem + kpad * RB;
@@ -179,6 +206,17 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
     // transposed-read lane roles: 16-lane group -> d sub-block, lane -> (key row, 4-column piece)
     const int tsub = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
     const bool ragged = (ntok & 31) != 0;
+    // Per-lane byte offsets of the fragment reads inside a 32-key block, fixed for the whole kernel (blocks start at
+    // multiples of 32 rows, so the row swizzles depend on the lane alone): a key step adds one block base per
+    // operand and reaches everything else through immediate offsets.
+    int kfrag[KS], vfrag[DB];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kfrag[ks] = r * RB + (((ks * 2 + hh) ^ kswz) << 4);
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+        vfrag[d] = (4 * hh + tq) * RB + (((d * 4 + tsub * 2 + (tp >> 1)) ^ v_swz(tq)) << 4) + (tp & 1) * 8;
+    // keys of the last block that exist (wave-uniform): a 16-key slice with none of them is skipped
+    const int tail_keys = ntok - (kblocks - 1) * 32;
 
     // One step of the key loop over NB (1 or 2) blocks of 32 keys: two blocks give two independent MFMA
     // chains and share one max exchange and one rescale decision.  lb = first block's index in the LDS
@@ -192,12 +230,13 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
             for (int i = 0; i < 16; ++i) s[u][i] = 0.f;
         }
         // S^T blocks: 32 keys x 32 queries each, K = head_dim in steps of 16
+        const char* kblk = k_lds + lb * (32 * RB);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
+            const char* kp = kblk + kfrag[ks];
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
-                const char* krow = k_lds + ((lb + u) * 32 + r) * RB;
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + (((ks * 2 + hh) ^ kswz) << 4));
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kp + u * (32 * RB));
                 s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[u], 0, 0, 0);
             }
         }
@@ -211,9 +250,10 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
 #pragma unroll
         for (int i = 3; i < 15; i += 2) mx = fmaxf(fmaxf(mx, s[0][i]), s[0][i + 1]);
         mx = fmaxf(mx, s[0][15]);
-        if constexpr (NB == 2) {
 #pragma unroll
-            for (int i = 0; i < 16; i += 2) mx = fmaxf(fmaxf(mx, s[1][i]), s[1][i + 1]);
+        for (int u = 1; u < NB; ++u) {
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) mx = fmaxf(fmaxf(mx, s[u][i]), s[u][i + 1]);
         }
         // The other half-wave holds the other 16 keys of each block for the same query.  The swap
         // exchanges lanes 32..63 of its first operand with lanes 0..31 of its second: each lane finds
@@ -242,16 +282,20 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
         // scheduling barrier: issued after them, the first P.V of every step would wait out the LDS latency)
         constexpr int G = NB * 2;
         bf16x4 vv[2][DB][2];
-        auto issue = [&](int g, bf16x4 (&dst)[DB][2]) {
-            const int u = g >> 1, st = g & 1;
-            const int ka = (lb + u) * 32 + 16 * st + 4 * hh + tq;
+        uint32_t vblk[DB];                  // this step's first V row for each 32-column block of O^T
+        if constexpr (OVL) {
+            const uint32_t vb = (uint32_t)(uintptr_t)(lds_void*)(v_lds + lb * (32 * RB));
+#pragma unroll
+            for (int d = 0; d < DB; ++d) vblk[d] = vb + (uint32_t)vfrag[d];
+        }
+        auto issue = [&](auto gc, bf16x4 (&dst)[DB][2]) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int off = ((g >> 1) * 32 + 16 * (g & 1)) * RB;      // 16-key slice g of the step
 #pragma unroll
             for (int d = 0; d < DB; ++d) {
-                const int chunk = d * 4 + tsub * 2 + (tp >> 1);
-                const char* a0 = v_lds + ka * RB + ((chunk ^ v_swz(ka)) << 4) + (tp & 1) * 8;
-                const uint32_t addr = (uint32_t)(uintptr_t)(lds_void*)a0;
-                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst[d][0]) : "v"(addr));
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst[d][1]) : "v"(addr), "n"(8 * RB));
+                const uint32_t addr = vblk[d];
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst[d][0]) : "v"(addr), "n"(off));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst[d][1]) : "v"(addr), "n"(off + 8 * RB));
             }
         };
         auto landed = [&](bf16x4 (&w)[DB][2], auto last_c) {
@@ -264,17 +308,25 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
                 else asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[2][0]), "+v"(w[2][1]));
             }
         };
+        // the last block's second 16-key slice holds no key at all when at most 16 of its keys exist (wave-uniform)
+        const bool skip_tail = gb + NB == kblocks && tail_keys <= 16;
         if constexpr (OVL) {
-            issue(0, vv[0]);
-            issue(1, vv[1]);
+            issue(std::integral_constant<int, 0>{}, vv[0]);
+            if (G > 2 || !skip_tail) issue(std::integral_constant<int, 1>{}, vv[1]);
         }
         float psum = 0.f;
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
+            if (OVL && u == NB - 1 && skip_tail) {
+                // keys 16..31 of the last block do not exist: their probabilities are never used
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                s[u][i] = __builtin_amdgcn_exp2f(fmaf(s[u][i], scale_log2e, -m_run));
-                if constexpr (!MSUM) psum += s[u][i];
+                for (int i = 0; i < 8; ++i) s[u][i] = __builtin_amdgcn_exp2f(fmaf(s[u][i], scale_log2e, -m_run));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    s[u][i] = __builtin_amdgcn_exp2f(fmaf(s[u][i], scale_log2e, -m_run));
+                    if constexpr (!MSUM) psum += s[u][i];
+                }
             }
         }
         if constexpr (!MSUM) l_run += psum;
@@ -286,14 +338,14 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
             // P.V of a head would wait for the whole staging of the next head.  Groups of 2 DB reads
             // (one 16-key slice) are issued two groups ahead of the MFMAs that use them (the first two before the
             // exponentials); the wait is tied to the group's registers so that the MFMAs cannot move above it.
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const int u = g >> 1, st = g & 1;
+            auto slice = [&](auto gc, auto last_c, auto gs_c) {
+                constexpr int g = decltype(gc)::value;
+                constexpr int GS = decltype(gs_c)::value;            // slices this step works through
+                constexpr int u = g >> 1, st = g & 1;
                 u32x4 pk = {pack_bf16(s[u][8 * st + 0], s[u][8 * st + 1]), pack_bf16(s[u][8 * st + 2], s[u][8 * st + 3]),
                             pack_bf16(s[u][8 * st + 4], s[u][8 * st + 5]), pack_bf16(s[u][8 * st + 6], s[u][8 * st + 7])};
                 const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
-                if (g + 1 < G) landed(vv[g & 1], std::false_type{});
-                else landed(vv[g & 1], std::true_type{});
+                landed(vv[g & 1], last_c);
                 // copies: the slot is refilled (slice g + 2) while these MFMAs are still being issued
                 bf16x8 vf[DB];
 #pragma unroll
@@ -301,7 +353,16 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
 #pragma unroll
                 for (int d = 0; d < DB; ++d) o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[d], pf, o_acc[d], 0, 0, 0);
                 l_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, l_acc, 0, 0, 0);
-                if (g + 2 < G) issue(g + 2, vv[g & 1]);
+                if constexpr (g + 2 < GS) issue(std::integral_constant<int, g + 2>{}, vv[g & 1]);
+            };
+            if (skip_tail) {
+                static_for<0, G - 1>([&](auto gc) {
+                    slice(gc, std::integral_constant<bool, decltype(gc)::value + 1 == G - 1>{}, std::integral_constant<int, G - 1>{});
+                });
+            } else {
+                static_for<0, G>([&](auto gc) {
+                    slice(gc, std::integral_constant<bool, decltype(gc)::value + 1 == G>{}, std::integral_constant<int, G>{});
+                });
             }
         } else {
 #pragma unroll
@@ -337,6 +398,8 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
     };
     using C1 = std::integral_constant<int, 1>;
     using C2 = std::integral_constant<int, 2>;
+    using C3 = std::integral_constant<int, 3>;
+    using C4 = std::integral_constant<int, 4>;
     const int kend = (VITK_ATTN_PROBE(probe) & 2) ? 0 : kblocks;      // probe bit 1: skip the key loop (timing only)
 
     // normalise and store one q-tile: lane holds q = qrow, d = 32*blk + 8g + 4*hh + (0..3)
@@ -410,14 +473,23 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
         for (int it = 0; bh < nbh; bh += gridDim.x, ++it) {
             // head bh has landed in buffer it & 1 (every wave waits for its own pieces, the barrier publishes
             // them), and every wave is done with head bh - gridDim.x, whose buffer the next head overwrites
+            VITK_ATTN_STAMP(0)
             __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0), through the builtin: the compiler's wait bookkeeping sees it
             __syncthreads();
+            VITK_ATTN_STAMP(1)
             const int nxt = bh + gridDim.x;
             bf16x8 qn[KS];
-            if (nxt < nbh) {                               // workgroup-uniform
+            if constexpr (LW) {
+                if (wave == NW) {                          // the loader wave: the next head's K and V, nothing else
+                    if (nxt < nbh) stage(smem + ((it + 1) & 1) * buf_bytes, 0, kpad / RPP, nxt, 0, 1);
+                    continue;
+                }
+                if (nxt < nbh) load_q(qn, nxt, wave * 32 + r);
+            } else if (nxt < nbh) {                        // workgroup-uniform
                 stage(smem + ((it + 1) & 1) * buf_bytes, 0, kpad / RPP, nxt);
                 load_q(qn, nxt, wave * 32 + r);
             }
+            VITK_ATTN_STAMP(2)
             k_lds = smem + (it & 1) * buf_bytes;
             v_lds = k_lds + kpad * RB;
             q0 = wave * 32;
@@ -427,10 +499,27 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
                 m_run = kMaskedScore;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) l_acc[i] = 0.f;
+                // Steps of up to four 32-key blocks: a step's time is set by its dependent chain (scores -> max -> exp ->
+                // P.V: a one-block step takes as long as a two-block one), so fewer, larger steps; four blocks of scores
+                // are what the registers of two waves per SIMD hold.
                 int kb = 0;
+                if constexpr (NBMAX == 4) {
+                    for (; kb + 4 <= kend; kb += 4) {
+                        key_step(kb, kb, C4{});
+                        VITK_ATTN_STAMP(3 + (kb >> 2 < 2 ? kb >> 2 : 2))
+                    }
+                } else if constexpr (NBMAX == 3) {
+                    // (a remainder of one block joins the last full step's neighbour: 7 blocks run as 3 + 2 + 2)
+                    for (; kb + 3 <= kend && kend - kb != 4; kb += 3) {
+                        key_step(kb, kb, C3{});
+                        VITK_ATTN_STAMP(3 + (kb / 3 < 2 ? kb / 3 : 2))
+                    }
+                }
                 for (; kb + 2 <= kend; kb += 2) key_step(kb, kb, C2{});
                 if (kb < kend) key_step(kb, kb, C1{});
+                VITK_ATTN_STAMP(6)
                 finish();
+                VITK_ATTN_STAMP(7)
                 q0 += NW * 32;
                 qrow = q0 + r;
                 if (q0 < ntok) {
@@ -467,7 +556,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd(const bf16_t* __restric
     }
 }
 
-template <int HD, int NW, bool VTR, bool STREAM, bool PD = false>
+template <int HD, int NW, bool VTR, bool STREAM, bool PD = false, bool LW = false>
 static hipError_t attn_launch(const void* q, const void* k, const void* v, void* out, int batch, int heads,
                               int ntok, float scale, hipStream_t s, float* lse, int probe) {
     const int kpad = ((ntok + 31) / 32) * 32;
@@ -477,14 +566,14 @@ static hipError_t attn_launch(const void* q, const void* k, const void* v, void*
                                     : (size_t)kpad * 128 + (size_t)64 * (kpad + 4) * 2;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {   // beyond the default dynamic-LDS limit the kernel must be told
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_fwd<HD, NW, VTR, STREAM, PD>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_fwd<HD, NW, VTR, STREAM, PD, LW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     const int qtiles = (ntok + 31) / 32;
     const int nbh = batch * heads;
-    dim3 grid(PD ? (nbh < num_cus() ? nbh : num_cus()) : nbh, STREAM ? (qtiles + NW - 1) / NW : 1), block(NW * 64);
-    hipLaunchKernelGGL((attention_fwd<HD, NW, VTR, STREAM, PD>), grid, block, lds, s,
+    dim3 grid(PD ? (nbh < num_cus() ? nbh : num_cus()) : nbh, STREAM ? (qtiles + NW - 1) / NW : 1), block((NW + (LW ? 1 : 0)) * 64);
+    hipLaunchKernelGGL((attention_fwd<HD, NW, VTR, STREAM, PD, LW>), grid, block, lds, s,
                        reinterpret_cast<const bf16_t*>(q), reinterpret_cast<const bf16_t*>(k),
                        reinterpret_cast<const bf16_t*>(v), reinterpret_cast<bf16_t*>(out), ntok, heads,
                        scale * 1.44269504088896340736f, probe, nbh, lse);
@@ -531,7 +620,7 @@ hipError_t launch_attention(const void* q, const void* k, const void* v, void* o
     if ((mode == 1 && (hd != 64 || !fits)) || (mode == 3 && !fits)) return hipErrorInvalidValue;
     if (mode == 0 && !fits) mode = 2;
     if (mode == 0 && !fits2) mode = 3;
-    const int probe = (variant >> 2) & 7;       // read by diagnostic builds only
+    const int probe = ((variant >> 2) & 7) | (((variant >> 10) & 1) << 3);       // read by diagnostic builds only
     // Waves per workgroup (one 32-row q-tile at a time each).  Resident K/V: one workgroup per head, its
     // waves take q-tiles round-robin (the width is chosen below).  Streamed: one q-tile per wave, fewest
     // workgroups per head, then fewest idle slots.
@@ -552,6 +641,7 @@ hipError_t launch_attention(const void* q, const void* k, const void* v, void* o
         const int forced = (variant >> 5) & 15;
         if ((forced >= 4 && forced <= 8) || ((forced == 10 || forced == 12) && mode != 2)) nw = forced;
     }
+    const bool no_loader = (variant >> 11) & 1;     // test hook: the persistent variant without its loader wave
 #define VITK_ATTN_CASE(NWV)                                                                                   \
     case NWV:                                                                                                 \
         if (hd == 96 && mode == 2) return attn_launch<96, NWV, true, true>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);  \
@@ -561,6 +651,7 @@ hipError_t launch_attention(const void* q, const void* k, const void* v, void* o
         if (hd == 80 && mode == 0) return attn_launch<80, NWV, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);  \
         if (hd == 80) return attn_launch<80, NWV, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);   \
         if (mode == 2) return attn_launch<64, NWV, true, true>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);   \
+        if (mode == 0 && NWV < 8 && !no_loader) return attn_launch<64, NWV, true, false, true, true>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);  \
         if (mode == 0) return attn_launch<64, NWV, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);  \
         if (mode == 3) return attn_launch<64, NWV, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);  \
         return attn_launch<64, NWV, false, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);

@@ -202,7 +202,7 @@ int vitk_layernorm_backward(const float* x, int64_t x_row_stride, const float* g
 
 /* Weight gradient of a Linear layer in the training step: C[m][n] = sum_r G[r][m] * X[r][n] (dW = dY^T X, what
  * autograd computes for nn.Linear at models/transformer.py:15,17,36,38).  G bf16 [R, M], X bf16 [R, N], both
- * contiguous; C f32 [M, N].  M, N multiples of 256, R of 64.  The k range is split over workgroups; the caller
+ * contiguous; C f32 [M, N].  M, N multiples of 256, any R >= 1 (rows past the last whole 64-row tile are masked inside the kernel).  The k range is split over workgroups; the caller
  * provides the scratch for the partial tiles: vitk_gemm_tn_workspace() floats (0 when no split is needed,
  * -1 for an unsupported shape).  Partials are added in a fixed order: results are reproducible. */
 int64_t vitk_gemm_tn_workspace(int M, int N, int R);

@@ -194,21 +194,29 @@ def test_gpu_layernorm_backward_kernel(rows, D, gdt):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("R,M,N", [(64, 256, 256), (256, 256, 512), (4096, 768, 256), (12608, 768, 768),
-                                   (50432, 3072, 768), (50432, 768, 3072), (50432, 2304, 768), (50432, 768, 768)])
+                                   (50432, 3072, 768), (50432, 768, 3072), (50432, 2304, 768), (50432, 768, 768),
+                                   # row counts that do not fill the last 64-row tile (batches of 5 and 3 images at 197
+                                   # tokens, single rows, one row more / fewer than a tile)
+                                   (985, 768, 768), (591, 2304, 768), (1, 256, 256), (63, 256, 256), (65, 256, 512),
+                                   (100, 256, 256), (50432 + 37, 768, 768), (12607, 3072, 768)])
 def test_gpu_weight_gradient_gemm(R, M, N):
     """vitk_gemm_tn (dW = dY^T X with the k range split over workgroups) against an fp64 product of the same
-    bf16 operands; reproducible run to run."""
+    bf16 operands; reproducible run to run.  The operands are views of larger buffers whose other rows hold NaN:
+    a kernel that read a row past the end of either operand would show it."""
     from vit_amd import ops
     gen = torch.Generator().manual_seed(R + M + N)
     g = (torch.randn(R, M, generator=gen) * 0.5).to(torch.bfloat16)
     x = torch.randn(R, N, generator=gen).to(torch.bfloat16)
-    gd, xd = g.cuda(), x.cuda()
+    gbig = torch.full((R + 70, M), float("nan"), dtype=torch.bfloat16, device="cuda")
+    xbig = torch.full((R + 70, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    gbig[:R], xbig[:R] = g.cuda(), x.cuda()
+    gd, xd = gbig[:R], xbig[:R]
     want = (gd.double().t() @ xd.double()).cpu()
     got = ops.gemm_tn(gd, xd)
     err = (got.cpu().double() - want).abs().max()
     assert err <= 1e-5 * (R ** 0.5) * 4 + 1e-6, f"max abs error {err:.3e}"
     assert torch.equal(got, ops.gemm_tn(gd, xd))
-    assert not ops.gemm_tn_supported(1000, 768, R) and not ops.gemm_tn_supported(768, 768, 100)
+    assert not ops.gemm_tn_supported(1000, 768, R) and ops.gemm_tn_supported(768, 768, 100)
     # the same launch with the bias gradient (column sums of g) fused in: identical product, sums vs fp64
     cs = torch.full((M,), float("nan"), device="cuda")
     got2 = ops.gemm_tn(gd, xd, colsum=cs)
@@ -349,15 +357,17 @@ def test_gpu_input_gradient_gemm_with_activation_derivative(M, N, K, act):
 
 
 @pytest.mark.gpu
-def test_gpu_no_library_gemm_or_aten_gelu_backward_on_the_bf16_training_path():
-    """One bf16 step of a 64-row-aligned configuration under the profiler: every GEMM of the backward is a
-    libvitk kernel (no hipBLASLt / rocBLAS `Cijk_` kernel, no aten gelu_backward, no fused-attention backward)."""
+@pytest.mark.parametrize("batch", [64, 5])
+def test_gpu_no_library_gemm_or_aten_gelu_backward_on_the_bf16_training_path(batch):
+    """One bf16 step under the profiler: every GEMM of the backward is a libvitk kernel (no hipBLASLt / rocBLAS
+    `Cijk_` kernel, no aten gelu_backward, no fused-attention backward), with 64 images x 65 tokens (whole 64-row
+    tiles) and with 5 images (325 rows: the weight-gradient GEMM masks its last K tile)."""
     import vit_amd
     from torch.profiler import ProfilerActivity, profile
     m = vit_amd.VisionTransformer(img_size=128, patches=16, num_classes=1000, hidden_size=256, num_layers=2, num_heads=4,
                                   norm=lambda d: torch.nn.LayerNorm(d, eps=1e-6)).cuda().train()
-    x = torch.randn(64, 3, 128, 128, device="cuda")                        # 64 images x 65 tokens: rows % 64 == 0
-    t = torch.randint(0, 1000, (64,), device="cuda")
+    x = torch.randn(batch, 3, 128, 128, device="cuda")
+    t = torch.randint(0, 1000, (batch,), device="cuda")
     crit = torch.nn.CrossEntropyLoss()
     crit(m(x), t).backward()
     m.zero_grad()

@@ -1,1 +1,1 @@
-timeout -k 10 200 python -u tools/attn_sweep.py --variant=0,0x800 --rounds=5 --launches=100 256 12 197 64 256 16 197 64 2>&1 | grep -v amdgpu.ids
+timeout -k 10 600 python -u -m pytest tests/test_train_step.py tests/test_train_ddp.py tests/test_gpu_fuzz.py -q -x -m gpu --timeout 300 --timeout-method thread -p no:cacheprovider 2>&1 | tail -8

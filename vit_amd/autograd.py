@@ -8,7 +8,7 @@ DistributedDataParallel work unchanged.  In the bf16 mode every gradient of the 
 kernel: LayerNorm backward, the weight-gradient GEMM (dW = dY^T X, which also sums dY's columns for the bias),
 attention backward, and the input gradients dX = dY W through the forward GEMM kernel on the transposed weight,
 with GELU' / tanh' in its epilogue.  torch operations remain for the fp32 mode's backward, for shapes the kernels
-do not take (rows that do not fill 64-row tiles, head sizes other than 64), for casts, slices and small
+do not take (widths that are not multiples of 256, head sizes other than 64), for casts, slices and small
 reductions, and for the masks (and, with attn_dropout > 0, the attention) of the training path with dropout.
 
 cd = compute dtype of the GEMM operands: torch.bfloat16, or torch.float32 in the fp32 mode.
@@ -33,19 +33,14 @@ def _operand(g, cd):
 
 
 def _weight_grad(g, a, bias=None):
-    """(f32 [out, in] = g^T a, bias gradient or None) for g [rows, out], a [rows, in]: the HIP split-k kernel on the
-    rows that fill whole 64-row K tiles (bf16, out and in multiples of 256), which sums g's columns in the same pass
-    when the layer has a bias; a small library product for the remaining rows."""
+    """(f32 [out, in] = g^T a, bias gradient or None) for g [rows, out], a [rows, in]: the HIP split-k kernel (bf16,
+    out and in multiples of 256; any row count: the kernel masks the rows past its last whole 64-row tile), which
+    sums g's columns in the same pass when the layer has a bias."""
     g, a = g.contiguous(), a.contiguous()
     rows = g.shape[0]
-    r64 = rows - rows % 64
-    if g.dtype == torch.bfloat16 and r64 > 0 and ops.gemm_tn_supported(g.shape[1], a.shape[1], r64):
+    if g.dtype == torch.bfloat16 and ops.gemm_tn_supported(g.shape[1], a.shape[1], rows):
         gb = None if bias is None else torch.empty(g.shape[1], dtype=torch.float32, device=g.device)
-        gw = ops.gemm_tn(g[:r64], a[:r64], colsum=gb)
-        if r64 < rows:
-            gw += (g[r64:].t() @ a[r64:]).float()
-            if gb is not None:
-                gb += g[r64:].sum(0, dtype=torch.float32)
+        gw = ops.gemm_tn(g, a, colsum=gb)
         return gw, (None if gb is None else gb.to(bias.dtype))
     return (g.t() @ a).float(), _bias_grad(g, bias)
 

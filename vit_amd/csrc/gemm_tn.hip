@@ -31,13 +31,17 @@
 
 namespace vitk {
 
+// A row of zeros: what the rows past the end of G read as in the last K tile when the row count is not a multiple of 64
+__device__ __attribute__((aligned(16))) uint32_t g_tn_zero_row[128 + 4];
+
 constexpr int kTnStage = 64 * 512;            // one operand K tile: 64 k-rows x 256 columns bf16
 constexpr int kTnLds = 4 * kTnStage;          // [G stage 0][G stage 1][X stage 0][X stage 1]
 
 template <bool COLSUM>
 __global__ __launch_bounds__(512, 2) void gemm_tn_partial(const bf16_t* __restrict__ G, const bf16_t* __restrict__ X,
                                                           float* __restrict__ part, float* __restrict__ colsum_part,
-                                                          int M, int N, int ldg, int ldx, int ktiles_total, int splits) {
+                                                          int M, int N, int ldg, int ldx, int ktiles_total, int splits,
+                                                          int tail_rows) {
     __shared__ __attribute__((aligned(1024))) char smem[kTnLds];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -75,8 +79,29 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_partial(const bf16_t* __restri
     const char* x_base = reinterpret_cast<const char*>(X) + (size_t)kt0 * 64 * ldx * 2;
     const size_t g_step = (size_t)64 * ldg * 2, x_step = (size_t)64 * ldx * 2;
     // piece i (0..7) of this wave's share of K tile kt: i < 4 a G piece, else an X piece
+    // tail_rows > 0: the last K tile of all holds only that many rows.  Its other rows read zeros for G (so they add
+    // nothing to any product or column sum) and re-read the last existing row for X (finite values).
+    const int kt_tail = tail_rows > 0 ? ktiles_total - 1 - kt0 : -1;        // this split's index of that K tile, if it has it
     auto issue_piece = [&](int stage, int kt, auto ic) {
         constexpr int i = decltype(ic)::value & 3;
+        if (kt == kt_tail) {                                     // wave-uniform, once per launch at most
+            const int k = 2 * (wave * 4 + i) + (lane >> 5);
+            const int p = lane & 31;
+            const int f = (k & 3) | (((k >> 3) & 1) << 2);
+            const int col = (((p >> 1) ^ f) << 4) + (p & 1) * 8;
+            if constexpr (decltype(ic)::value < 4) {
+                char* dg = smem + stage * kTnStage + (wave * 4 + i) * 1024;
+                const char* src = k < tail_rows ? g_base + kt * g_step + g_off[i]
+                                                : reinterpret_cast<const char*>(g_tn_zero_row) + (col & 127) * 2;
+                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dg, 16, 0, 0);
+            } else {
+                char* dx = smem + 2 * kTnStage + stage * kTnStage + (wave * 4 + i) * 1024;
+                const int kc = k < tail_rows ? k : tail_rows - 1;
+                const char* src = x_base + kt * x_step + ((uint32_t)kc * ldx + n0 + col) * 2u;
+                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dx, 16, 0, 0);
+            }
+            return;
+        }
         if constexpr (decltype(ic)::value < 4) {
             char* dg = smem + stage * kTnStage + (wave * 4 + i) * 1024;
             __builtin_amdgcn_global_load_lds((gbl_void*)(g_base + kt * g_step + g_off[i]), (lds_void*)dg, 16, 0, 0);
@@ -230,7 +255,7 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce(const float* __restrict__ 
 
 // number of k splits: one workgroup per CU where the k range allows (at least 4 K tiles per split)
 int gemm_tn_splits(int M, int N, int R) {
-    const int tiles = (M >> 8) * (N >> 8), ktiles = R / 64;
+    const int tiles = (M >> 8) * (N >> 8), ktiles = (R + 63) / 64;
     if (tiles <= 0 || ktiles <= 0) return 0;
     int s = num_cus() / tiles;
     if (s < 1) s = 1;
@@ -248,10 +273,10 @@ hipError_t launch_gemm_tn(const void* G, const void* X, float* C, float* colsum,
     float* cs_part = colsum ? (splits == 1 ? colsum : part + (size_t)splits * M * N) : nullptr;
     if (colsum)
         hipLaunchKernelGGL(gemm_tn_partial<true>, dim3(grid), dim3(512), 0, s, reinterpret_cast<const bf16_t*>(G),
-                           reinterpret_cast<const bf16_t*>(X), splits == 1 ? C : part, cs_part, M, N, ldg, ldx, R / 64, splits);
+                           reinterpret_cast<const bf16_t*>(X), splits == 1 ? C : part, cs_part, M, N, ldg, ldx, (R + 63) / 64, splits, R & 63);
     else
         hipLaunchKernelGGL(gemm_tn_partial<false>, dim3(grid), dim3(512), 0, s, reinterpret_cast<const bf16_t*>(G),
-                           reinterpret_cast<const bf16_t*>(X), splits == 1 ? C : part, cs_part, M, N, ldg, ldx, R / 64, splits);
+                           reinterpret_cast<const bf16_t*>(X), splits == 1 ? C : part, cs_part, M, N, ldg, ldx, (R + 63) / 64, splits, R & 63);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || splits == 1) return e;
     const size_t mn4 = (size_t)M * N / 4;

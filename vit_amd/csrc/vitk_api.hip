@@ -415,7 +415,7 @@ int vitk_layernorm_backward(const float* x, int64_t x_row_stride, const float* g
 }
 
 int64_t vitk_gemm_tn_workspace(int M, int N, int R) {
-    if (M <= 0 || N <= 0 || R <= 0 || M % 256 || N % 256 || R % 64) return -1;
+    if (M <= 0 || N <= 0 || R <= 0 || M % 256 || N % 256) return -1;
     const int splits = gemm_tn_splits(M, N, R);
     return splits <= 1 ? 0 : (int64_t)splits * M * N;
 }
@@ -423,8 +423,8 @@ int64_t vitk_gemm_tn_workspace(int M, int N, int R) {
 static int gemm_tn_checked(const char* name, const void* G, const void* X, float* C, float* colsum, float* workspace,
                            int64_t workspace_floats, int64_t need, int M, int N, int R, void* stream) {
     if (!G || !X || !C) return fail(VITK_ERR_INVALID, "%s: null pointer", name);
-    if (M <= 0 || N <= 0 || R <= 0 || M % 256 || N % 256 || R % 64)
-        return fail(VITK_ERR_UNSUPPORTED, "%s: M=%d N=%d R=%d (M, N multiples of 256, R of 64)", name, M, N, R);
+    if (M <= 0 || N <= 0 || R <= 0 || M % 256 || N % 256)
+        return fail(VITK_ERR_UNSUPPORTED, "%s: M=%d N=%d R=%d (M, N multiples of 256)", name, M, N, R);
     if ((int64_t)R * (M > N ? M : N) * 2 >= ((int64_t)1 << 32))
         return fail(VITK_ERR_UNSUPPORTED, "%s: operand of 4 GiB or more", name);
     if (need > 0 && (!workspace || workspace_floats < need))
@@ -441,7 +441,7 @@ int vitk_gemm_tn(const void* G, const void* X, float* C, float* workspace, int64
 }
 
 int64_t vitk_gemm_tn_colsum_workspace(int M, int N, int R) {
-    if (M <= 0 || N <= 0 || R <= 0 || M % 256 || N % 256 || R % 64) return -1;
+    if (M <= 0 || N <= 0 || R <= 0 || M % 256 || N % 256) return -1;
     const int splits = gemm_tn_splits(M, N, R);
     return splits <= 1 ? 0 : (int64_t)splits * M * N + (int64_t)splits * M;
 }

@@ -428,7 +428,7 @@ def gemm_tn(g, x, out=None, colsum=None):
     N = x.shape[1]
     need = (L.vitk_gemm_tn_workspace if colsum is None else L.vitk_gemm_tn_colsum_workspace)(M, N, R)
     if need < 0:
-        raise _lib.VitkError(f"gemm_tn: unsupported shape M={M} N={N} R={R} (M, N multiples of 256, R of 64)")
+        raise _lib.VitkError(f"gemm_tn: unsupported shape M={M} N={N} R={R} (M, N multiples of 256)")
     key = _scratch_key(g.device)
     ws = _tn_workspace.get(key)
     if need > 0 and (ws is None or ws.numel() < need):

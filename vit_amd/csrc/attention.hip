@@ -515,7 +515,10 @@ __global__ __launch_bounds__((NW + (LW ? 1 : 0)) * 64) void attention_fwd(const 
                         VITK_ATTN_STAMP(3 + (kb / 3 < 2 ? kb / 3 : 2))
                     }
                 }
-                for (; kb + 2 <= kend; kb += 2) key_step(kb, kb, C2{});
+                for (; kb + 2 <= kend; kb += 2) {
+                    key_step(kb, kb, C2{});
+                    VITK_ATTN_STAMP(3 + (kb >> 1 < 2 ? kb >> 1 : 2))
+                }
                 if (kb < kend) key_step(kb, kb, C1{});
                 VITK_ATTN_STAMP(6)
                 finish();

@@ -262,6 +262,23 @@ int vitk_colsum_bf16(const void* G, float* out, float* partials, int partial_row
  * host logic of this library, exposed so that it can be tested without a GPU. */
 int vitk_gemm_plan(int M, int N, int K, int cus, int* plan);
 
+/* ---- the last block evaluated for the cls token only --------------------------------------------------
+ * Encoder.forward keeps token 0 of the last block's output (models/transformer.py:98-99), and past the last block's
+ * attention every op is per token: its out_proj, norm2, MLP and all but the cls query of its attention feed nothing.
+ * These two entry points let a caller compute just that row per image with the arithmetic of the full launch. */
+
+/* vitk_attention for the query rows below nrows only (whole 32-row tiles are computed; the other rows of ctx are
+ * left untouched).  Tiling and summation order are those of vitk_attention: a computed row equals the full launch's. */
+int vitk_attention_rows(const void* q, const void* k, const void* v, void* ctx, int batch, int heads, int ntok, int hd,
+                        float scale, int nrows, void* stream);
+
+/* vitk_gemm_bias_residual on strided rows: row m of A at A + m*lda, of resid and out at + m*ldo (elements; lda >= K a
+ * multiple of 8, ldo >= N a multiple of 4).  With lda = ldo = ntok * D and M = batch it updates the cls rows of the
+ * residual stream in place from the cls rows of ctx (out_proj, models/transformer.py:47,72) or of a [batch, M] tensor
+ * (fc2, :24,76). */
+int vitk_gemm_bias_residual_strided(const void* A, int64_t lda, const void* W, const float* bias, const float* resid,
+                                    float* out, int64_t ldo, int M, int N, int K, void* stream);
+
 /* ---- LayerNorm folded into the GEMMs either side of it (inference path) ----------------------------
  * Encoder1DBlock computes x = x + out_proj(..); y = norm2(x); h = gelu(fc1(y)) and x = x + fc2(h); y = norm1(x);
  * qkv = in_proj(y) (models/transformer.py:66-76, :40-48, :20-26).  With these four entry points the LayerNorm

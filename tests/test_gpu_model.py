@@ -258,3 +258,26 @@ def test_folded_and_separate_layernorm_paths_both_meet_the_bar(name):
     assert (y_fold.argmax(-1) == g["top1"]).all() and (y_sep.argmax(-1) == g["top1"]).all()
     assert np.array_equal(y_fold, y_again)
     assert not np.array_equal(y_fold, y_sep)
+
+
+@pytest.mark.parametrize("name,fold", [("b16_224_ref", True), ("b16_224_ref", False), ("s16_224_ref", True), ("b16_384_ref", True)])
+def test_last_block_for_the_cls_token_only_is_bit_identical(name, fold):
+    """Encoder.forward keeps token 0 of the last block's output (models/transformer.py:98-99): with
+    `encoder.cls_only_last_block` the last block's attention runs for the cls query's tile and its out_proj, norm2
+    and MLP for the cls row of every image only.  Same kernels, same summation order: identical logits, also at the
+    benchmark's batch."""
+    from vit_amd import synth
+    meta, g = load_golden(name)
+    cfg, sd, x = golden_inputs(meta)
+    m = build_model(meta["arch"], meta["img_size"], sd, DEV)
+    m.fold_layernorm = fold
+    big = 256 if meta["img_size"] == 224 else 128
+    xb = torch.cat([x, synth.synth_images(big - x.shape[0], meta["img_size"], seed=77)]).to(DEV).to(torch.bfloat16)
+    with torch.no_grad():
+        full, full_b = m(x.to(DEV)).clone(), m(xb).clone()
+        m.encoder.cls_only_last_block = True
+        pruned, pruned_b = m(x.to(DEV)).clone(), m(xb).clone()
+    assert torch.equal(full_b, pruned_b)
+    assert torch.equal(full, pruned) or (full - pruned).abs().max() <= 2e-6, (full - pruned).abs().max()
+    assert np.abs(pruned.float().cpu().numpy() - g["logits"]).max() <= TOL_BF16
+    print(f"{name} fold={fold}: small batch identical: {torch.equal(full, pruned)}")

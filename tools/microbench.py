@@ -83,6 +83,21 @@ def main():
         flops=2.0 * R * D * D)
     rec("fc1 + bias + GELU", timeit(lambda: ops.gemm_bias_gelu(y, w_fc1, b_m, h), it), flops=2.0 * R * M * D)
     rec("fc2 + residual", timeit(lambda: ops.gemm_bias_residual(h, w_fc2, b_d, x, x), it), flops=2.0 * R * M * D)
+    # the same GEMMs with the LayerNorm between them folded in (what the inference path of models up to 24 layers runs)
+    stats = torch.empty(R, D // 64, 2, dtype=f32, device=dev)
+    ab = torch.empty(R, 2, dtype=f32, device=dev)
+    cs_q, c_q = rn(3 * D, dt=f32), rn(3 * D, dt=f32)
+    cs_m, c_m = rn(M, dt=f32), rn(M, dt=f32)
+    if ops.ln_fold_ok(R, D, M):
+        rec("out_proj + residual + LN stats", timeit(lambda: ops.gemm_bias_residual_ln(ctx.view(R, D), w_out, b_d, x, x, y, stats), it),
+            flops=2.0 * R * D * D)
+        rec("ln_finalize", timeit(lambda: ops.ln_finalize(stats, ab, D, 1e-6), it), bytes_=R * (D // 64) * 8 + R * 8)
+        rec("fc1 (LN folded) + GELU", timeit(lambda: ops.gemm_ln_bias_gelu(y, w_fc1, ab, cs_m, c_m, h), it),
+            flops=2.0 * R * M * D)
+        rec("fc2 + residual + LN stats", timeit(lambda: ops.gemm_bias_residual_ln(h, w_fc2, b_d, x, x, y, stats), it),
+            flops=2.0 * R * M * D)
+        rec("qkv_proj (LN folded)", timeit(lambda: ops.qkv_proj_ln(y, w_qkv, ab, cs_q, c_q, qkv, B, N, H, hd), it),
+            flops=2.0 * R * 3 * D * D)
     o16 = torch.empty(R, D, dtype=bf, device=dev)
     rec("gemm_bias bf16 (DxD, no epilogue math)", timeit(lambda: ops.gemm_bias(y, w_out, b_d, o16), it),
         flops=2.0 * R * D * D)

@@ -82,7 +82,7 @@ __global__ __launch_bounds__((NW + (LW ? 1 : 0)) * 64) void attention_fwd(const 
                                                          const bf16_t* __restrict__ V,
                                                          bf16_t* __restrict__ O, int ntok, int heads,
                                                          float scale_log2e, int probe, int nbh,
-                                                         float* __restrict__ lse) {
+                                                         float* __restrict__ lse, int qrows) {
     static_assert(HD == 64 || ((HD == 96 || HD == 80) && VTR), "head_dim 64, or 80 / 96 with transposed LDS reads");
     static_assert(VTR || !STREAM, "streaming needs the transposed LDS reads");
     static_assert(!PD || (VTR && !STREAM), "the persistent variant stages whole heads by LDS-DMA");
@@ -450,7 +450,7 @@ __global__ __launch_bounds__((NW + (LW ? 1 : 0)) * 64) void attention_fwd(const 
     };
 
     if constexpr (STREAM) {
-        const bool active = q0 < ntok;   // wave-uniform: a wave whose whole q-tile is padding only takes part in staging
+        const bool active = q0 < qrows;  // wave-uniform: a wave whose whole q-tile is padding (or not asked for) only takes part in staging
 #pragma unroll
         for (int i = 0; i < 16; ++i) l_acc[i] = 0.f;
         const int nchunks = (kblocks + 1) >> 1;
@@ -494,7 +494,7 @@ __global__ __launch_bounds__((NW + (LW ? 1 : 0)) * 64) void attention_fwd(const 
             v_lds = k_lds + kpad * RB;
             q0 = wave * 32;
             qrow = q0 + r;
-            while (q0 < ntok) {                            // wave-uniform
+            while (q0 < qrows) {                           // wave-uniform
                 clear_o();
                 m_run = kMaskedScore;
 #pragma unroll
@@ -525,7 +525,7 @@ __global__ __launch_bounds__((NW + (LW ? 1 : 0)) * 64) void attention_fwd(const 
                 VITK_ATTN_STAMP(7)
                 q0 += NW * 32;
                 qrow = q0 + r;
-                if (q0 < ntok) {
+                if (q0 < qrows) {
                     // (more q-tiles than waves.)  Waiting here, not at the first use, keeps the key loop free
                     // of vector-memory waits, which would also wait for the next head's LDS-DMA.
                     load_q(qf, bh, qrow);
@@ -540,14 +540,14 @@ __global__ __launch_bounds__((NW + (LW ? 1 : 0)) * 64) void attention_fwd(const 
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed
         __syncthreads();
-        while (q0 < ntok) {                                // wave-uniform
+        while (q0 < qrows) {                               // wave-uniform
             int kb = 0;
             for (; kb + 2 <= kend; kb += 2) key_step(kb, kb, C2{});
             if (kb < kend) key_step(kb, kb, C1{});
             finish();
             q0 += NW * 32;
             qrow = q0 + r;
-            if (q0 < ntok) {
+            if (q0 < qrows) {
                 load_q(qf, bh, qrow);
                 clear_o();
                 m_run = kMaskedScore;
@@ -561,7 +561,7 @@ __global__ __launch_bounds__((NW + (LW ? 1 : 0)) * 64) void attention_fwd(const 
 
 template <int HD, int NW, bool VTR, bool STREAM, bool PD = false, bool LW = false>
 static hipError_t attn_launch(const void* q, const void* k, const void* v, void* out, int batch, int heads,
-                              int ntok, float scale, hipStream_t s, float* lse, int probe) {
+                              int ntok, float scale, hipStream_t s, float* lse, int probe, int qrows) {
     const int kpad = ((ntok + 31) / 32) * 32;
     const int rb = HD == 64 ? 128 : 256;
     const size_t lds = STREAM ? (size_t)4 * 64 * rb
@@ -579,7 +579,7 @@ static hipError_t attn_launch(const void* q, const void* k, const void* v, void*
     hipLaunchKernelGGL((attention_fwd<HD, NW, VTR, STREAM, PD, LW>), grid, block, lds, s,
                        reinterpret_cast<const bf16_t*>(q), reinterpret_cast<const bf16_t*>(k),
                        reinterpret_cast<const bf16_t*>(v), reinterpret_cast<bf16_t*>(out), ntok, heads,
-                       scale * 1.44269504088896340736f, probe, nbh, lse);
+                       scale * 1.44269504088896340736f, probe, nbh, lse, qrows);
     return hipGetLastError();
 }
 
@@ -611,8 +611,11 @@ int attention_pick_waves(int tiles, int max_waves) {
 }
 
 hipError_t launch_attention(const void* q, const void* k, const void* v, void* out, int batch, int heads,
-                            int ntok, int hd, float scale, int variant, hipStream_t s, float* lse) {
+                            int ntok, int hd, float scale, int variant, hipStream_t s, float* lse, int qrows) {
     if ((hd != 64 && hd != 80 && hd != 96) || ntok < 1) return hipErrorInvalidValue;
+    // qrows: only the query rows below it are computed (whole 32-row tiles); the tiling, and so every computed row's
+    // arithmetic, is that of the full launch
+    if (qrows <= 0 || qrows > ntok) qrows = ntok;
     const int qtiles = (ntok + 31) / 32;
     // variant: 0 = automatic (persistent workgroups with two resident K/V buffers when two heads fit in LDS,
     // one head per workgroup when one fits, else K/V streamed in 64-key chunks); 1 = resident, V stored
@@ -647,17 +650,17 @@ hipError_t launch_attention(const void* q, const void* k, const void* v, void* o
     const bool no_loader = (variant >> 11) & 1;     // test hook: the persistent variant without its loader wave
 #define VITK_ATTN_CASE(NWV)                                                                                   \
     case NWV:                                                                                                 \
-        if (hd == 96 && mode == 2) return attn_launch<96, NWV, true, true>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);  \
-        if (hd == 96 && mode == 0) return attn_launch<96, NWV, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);  \
-        if (hd == 96) return attn_launch<96, NWV, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);   \
-        if (hd == 80 && mode == 2) return attn_launch<80, NWV, true, true>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);  \
-        if (hd == 80 && mode == 0) return attn_launch<80, NWV, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);  \
-        if (hd == 80) return attn_launch<80, NWV, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);   \
-        if (mode == 2) return attn_launch<64, NWV, true, true>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);   \
-        if (mode == 0 && NWV < 8 && !no_loader) return attn_launch<64, NWV, true, false, true, true>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);  \
-        if (mode == 0) return attn_launch<64, NWV, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);  \
-        if (mode == 3) return attn_launch<64, NWV, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);  \
-        return attn_launch<64, NWV, false, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);
+        if (hd == 96 && mode == 2) return attn_launch<96, NWV, true, true>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe, qrows);  \
+        if (hd == 96 && mode == 0) return attn_launch<96, NWV, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe, qrows);  \
+        if (hd == 96) return attn_launch<96, NWV, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe, qrows);   \
+        if (hd == 80 && mode == 2) return attn_launch<80, NWV, true, true>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe, qrows);  \
+        if (hd == 80 && mode == 0) return attn_launch<80, NWV, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe, qrows);  \
+        if (hd == 80) return attn_launch<80, NWV, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe, qrows);   \
+        if (mode == 2) return attn_launch<64, NWV, true, true>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe, qrows);   \
+        if (mode == 0 && NWV < 8 && !no_loader) return attn_launch<64, NWV, true, false, true, true>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe, qrows);  \
+        if (mode == 0) return attn_launch<64, NWV, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe, qrows);  \
+        if (mode == 3) return attn_launch<64, NWV, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe, qrows);  \
+        return attn_launch<64, NWV, false, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe, qrows);
     switch (nw) {
         VITK_ATTN_CASE(4)
         VITK_ATTN_CASE(5)
@@ -666,13 +669,13 @@ hipError_t launch_attention(const void* q, const void* k, const void* v, void* o
         VITK_ATTN_CASE(8)
         case 10:      // resident modes only
             // (head_dim 80 / 96 with two resident heads has at most 5 q-tiles: never 10 waves)
-            if (hd == 96) return attn_launch<96, 10, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);
-            if (hd == 80) return attn_launch<80, 10, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);
-            if (mode == 0) return attn_launch<64, 10, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);
-            if (mode == 3) return attn_launch<64, 10, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);
-            return attn_launch<64, 10, false, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);
+            if (hd == 96) return attn_launch<96, 10, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe, qrows);
+            if (hd == 80) return attn_launch<80, 10, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe, qrows);
+            if (mode == 0) return attn_launch<64, 10, true, false, true>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe, qrows);
+            if (mode == 3) return attn_launch<64, 10, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe, qrows);
+            return attn_launch<64, 10, false, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe, qrows);
         case 12:      // one resident head per workgroup, head_dim 64 only
-            if (hd == 64 && mode == 3) return attn_launch<64, 12, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe);
+            if (hd == 64 && mode == 3) return attn_launch<64, 12, true, false>(q, k, v, out, batch, heads, ntok, scale, s, lse, probe, qrows);
             return hipErrorInvalidValue;
     }
 #undef VITK_ATTN_CASE

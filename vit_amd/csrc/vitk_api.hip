@@ -70,7 +70,7 @@ int dense(const char* name, const void* A, const void* W, const float* bias, con
 
 extern "C" {
 
-int vitk_version(void) { return 8; }
+int vitk_version(void) { return 9; }
 
 const char* vitk_last_error(void) { return g_err; }
 
@@ -276,7 +276,7 @@ int vitk_qkv_proj_ln(const void* A, const void* Wg, const float* ab, const float
 }
 
 static int attention_forward(const char* name, const void* q, const void* k, const void* v, void* ctx, float* lse,
-                             int batch, int heads, int ntok, int hd, float scale, void* stream) {
+                             int batch, int heads, int ntok, int hd, float scale, void* stream, int qrows = 0) {
     if (!q || !k || !v || !ctx) return fail(VITK_ERR_INVALID, "%s: null pointer", name);
     if (batch <= 0 || heads <= 0 || ntok <= 0) return fail(VITK_ERR_INVALID, "%s: non-positive size", name);
     if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(ctx))
@@ -287,8 +287,36 @@ static int attention_forward(const char* name, const void* q, const void* k, con
         return fail(VITK_ERR_UNSUPPORTED, "%s: ntok=%d exceeds the limit %d at hd=%d", name, ntok,
                     attention_max_tokens(hd), hd);
     return launched(launch_attention(q, k, v, ctx, batch, heads, ntok, hd, scale, g_attn_variant,
-                                     reinterpret_cast<hipStream_t>(stream), lse),
+                                     reinterpret_cast<hipStream_t>(stream), lse, qrows),
                     name);
+}
+
+int vitk_attention_rows(const void* q, const void* k, const void* v, void* ctx, int batch, int heads, int ntok, int hd,
+                        float scale, int nrows, void* stream) {
+    if (nrows < 1 || nrows > ntok) return fail(VITK_ERR_INVALID, "vitk_attention_rows: nrows=%d outside 1..%d", nrows, ntok);
+    return attention_forward("vitk_attention_rows", q, k, v, ctx, nullptr, batch, heads, ntok, hd, scale, stream, nrows);
+}
+
+int vitk_gemm_bias_residual_strided(const void* A, int64_t lda, const void* W, const float* bias, const float* resid,
+                                    float* out, int64_t ldo, int M, int N, int K, void* stream) {
+    const char* name = "vitk_gemm_bias_residual_strided";
+    if (!A || !W || !resid || !out) return fail(VITK_ERR_INVALID, "%s: null pointer", name);
+    if (M <= 0 || N <= 0 || K <= 0) return fail(VITK_ERR_INVALID, "%s: non-positive size %dx%dx%d", name, M, N, K);
+    if (!aligned16(A) || !aligned16(W) || !aligned16(out) || !aligned16(resid) || (bias && !aligned16(bias)))
+        return fail(VITK_ERR_INVALID, "%s: pointers must be 16-byte aligned", name);
+    if (lda < K || ldo < N || lda % 8 != 0 || ldo % 4 != 0)
+        return fail(VITK_ERR_INVALID, "%s: lda=%lld ldo=%lld (at least K / N, multiples of 8 / 4 elements)", name, (long long)lda, (long long)ldo);
+    if (K % 32 != 0) return fail(VITK_ERR_UNSUPPORTED, "%s: K=%d is not a multiple of 32", name, K);
+    if ((int64_t)(M + 256) * ldo * 4 >= ((int64_t)1 << 32) || (int64_t)(M + 256) * lda * 2 >= ((int64_t)1 << 32))
+        return fail(VITK_ERR_UNSUPPORTED, "%s: rows x stride of 4 GiB or more", name);
+    GemmArgs a = {};
+    a.A = A; a.W = W; a.bias = bias; a.out = out; a.resid = resid;
+    a.M = M; a.N = N; a.K = K; a.lda = (int)lda; a.ldo = (int)ldo;
+    a.order = g_gemm_variant >> 4;
+    const bool tiled_ok = (N % 256 == 0) && (K % 64 == 0) && M >= 128 && (g_gemm_variant & 15) != 2;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (tiled_ok) return launched(launch_gemm_tiled(a, EPI_BIAS_RESID_F32, false, g_gemm_variant & 15, s), name);
+    return launched(launch_gemm_small(a, EPI_BIAS_RESID_F32, s), name);
 }
 
 int vitk_attention(const void* q, const void* k, const void* v, void* ctx, int batch, int heads, int ntok,

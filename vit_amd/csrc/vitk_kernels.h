@@ -78,7 +78,7 @@ hipError_t launch_cast_f32_bf16(const float* in, void* out, int64_t n, hipStream
 int attention_pick_waves(int tiles, int max_waves);
 int attention_max_tokens(int hd);
 hipError_t launch_attention(const void* q, const void* k, const void* v, void* out, int batch, int heads,
-                            int ntok, int hd, float scale, int variant, hipStream_t s, float* lse = nullptr);
+                            int ntok, int hd, float scale, int variant, hipStream_t s, float* lse = nullptr, int qrows = 0);
 
 int attention_bwd_max_tokens();
 hipError_t launch_attention_backward(const void* q, const void* k, const void* v, const void* o, const void* d_o,

@@ -269,17 +269,36 @@ def qkv_proj(a, w, bias, qkv, batch, ntok, heads, hd):
     return qkv
 
 
-def attention(qkv, ctx, scale):
-    """qkv bf16 [3, B, H, N, hd] -> ctx bf16 [B, N, H*hd]."""
+def attention(qkv, ctx, scale, rows=None):
+    """qkv bf16 [3, B, H, N, hd] -> ctx bf16 [B, N, H*hd]; with `rows` only the query rows below it are computed
+    (whole 32-row tiles; the rest of ctx is left as it was)."""
     L = _lib.load()
     _chk(qkv, torch.bfloat16, "qkv"); _chk(ctx, torch.bfloat16, "ctx")
     _, B, H, N, hd = qkv.shape
     if tuple(ctx.shape) != (B, N, H * hd):
         raise _lib.VitkError(f"attention: ctx {tuple(ctx.shape)} vs [{B},{N},{H * hd}]")
     with _span("attention"):
-        _lib.check(L.vitk_attention(_ptr(qkv[0]), _ptr(qkv[1]), _ptr(qkv[2]), _ptr(ctx), B, H, N, hd,
-                                    float(scale), _stream()), L)
+        if rows is None:
+            _lib.check(L.vitk_attention(_ptr(qkv[0]), _ptr(qkv[1]), _ptr(qkv[2]), _ptr(ctx), B, H, N, hd,
+                                        float(scale), _stream()), L)
+        else:
+            _lib.check(L.vitk_attention_rows(_ptr(qkv[0]), _ptr(qkv[1]), _ptr(qkv[2]), _ptr(ctx), B, H, N, hd,
+                                             float(scale), int(rows), _stream()), L)
     return ctx
+
+
+def gemm_bias_residual_rows(a, lda, w, bias, x, ldo, rows):
+    """x[m*ldo : m*ldo + N] += a[m*lda : m*lda + K] @ w.T + bias for m < rows: the residual update on every ldo-th
+    row of the f32 stream x (in place) from every lda-th row of the bf16 tensor a."""
+    L = _lib.load()
+    _chk(a, torch.bfloat16, "A"); _chk(w, torch.bfloat16, "W"); _chk(bias, torch.float32, "bias"); _chk(x, torch.float32, "x")
+    N, K = w.shape
+    if a.numel() < (rows - 1) * lda + K or x.numel() < (rows - 1) * ldo + N:
+        raise _lib.VitkError(f"gemm_bias_residual_rows: {rows} rows at strides {lda} / {ldo} do not fit A {tuple(a.shape)} / x {tuple(x.shape)}")
+    with _span("gemm_bias_residual"):
+        _lib.check(L.vitk_gemm_bias_residual_strided(_ptr(a), lda, _ptr(w), _ptr(bias), _ptr(x), _ptr(x), ldo, rows, N, K,
+                                                     _stream()), L)
+    return x
 
 
 # ---- fp32 compute mode (vitk_*_f32) ------------------------------------------------------------

@@ -123,6 +123,10 @@ class Encoder(nn.Module):
         # the previous block's fc2) and norm2 (statistics from out_proj)
         mode = os.environ.get("VIT_AMD_LN_FOLD_MODE", "both")
         self.fold_norm1, self.fold_norm2 = mode in ("both", "ln1"), mode in ("both", "ln2")
+        # Inference, bf16 mode: evaluate the last block past its q/k/v projection for the cls token only (exact: the
+        # encoder returns token 0, and those ops are per token).  Off by default: the full block is what the
+        # reference's forward computes and what the throughput figures count.
+        self.cls_only_last_block = False
 
     def fold_ok(self, ws):
         """Whether the LayerNorms between the blocks' GEMMs can be folded into them (bf16 mode, shapes of the
@@ -131,6 +135,20 @@ class Encoder(nn.Module):
             return False
         B, N, D = ws.x.shape
         return ops.ln_fold_ok(B * N, D, self.blocks[0].mlp.fc1.out_features)
+
+    def _last_block_cls_rows(self, ws, w, p, blk):
+        """What is left of the last block after its q/k/v projection when only token 0 of its output is kept
+        (models/transformer.py:98-99): attention for the cls query, then out_proj, norm2 and the MLP on the cls row of
+        every image (every op past the attention is per token).  The same kernels as the full block on strided rows:
+        the cls rows of ws.x end up bit-identical to the full block's."""
+        B, N, D = ws.x.shape
+        M = blk.mlp.fc1.out_features
+        ops.attention(ws.qkv, ws.ctx, blk.attention.scaling, rows=1)
+        ops.gemm_bias_residual_rows(ws.ctx, N * D, w[p + "out.w"], w[p + "out.b"], ws.x, N * D, B)
+        y_cls, h_cls = ws.y[:B], ws.h[:B]
+        ops.layernorm(ws.x, w[p + "norm2.w"], w[p + "norm2.b"], _eps_of(blk.norm2), y_cls, rows=B, x_row_stride=N * D)
+        ops.gemm_bias_gelu(y_cls, w[p + "fc1.w"], w[p + "fc1.b"], h_cls)
+        ops.gemm_bias_residual_rows(h_cls, M, w[p + "fc2.w"], w[p + "fc2.b"], ws.x, N * D, B)
 
     def _blocks_folded(self, ws, w, stage_hook):
         """The blocks with every LayerNorm but the first folded into its neighbours: the residual GEMM before it
@@ -151,8 +169,13 @@ class Encoder(nn.Module):
             else:
                 ops.layernorm(x2, w[p + "norm1.w"], w[p + "norm1.b"], _eps_of(blk.norm1), ws.y)
                 ops.qkv_proj(ws.y, w[p + "qkv.w"], w[p + "qkv.b"], ws.qkv, B, N, H, hd)
+            if i == last and self.cls_only_last_block:
+                self._last_block_cls_rows(ws, w, p, blk)
+                if i == 0 and stage_hook is not None:
+                    stage_hook("block0", ws.x)
+                break
             ops.attention(ws.qkv, ws.ctx, blk.attention.scaling)
-            if fold2:
+            if fold2 and i < last:       # (the last block keeps its norm2 launch: the cls-only form above shares its kernels)
                 ops.gemm_bias_residual_ln(ws.ctx.view(B * N, D), w[p + "out.w"], w[p + "out.b"], x2, x2, ws.y, ws.ln_stats)
                 ops.ln_finalize(ws.ln_stats, ws.ln_ab, D, _eps_of(blk.norm2))
                 ops.gemm_ln_bias_gelu(ws.y, w[p + "fc1.wg"], ws.ln_ab, w[p + "fc1.s"], w[p + "fc1.c"], ws.h)
@@ -178,7 +201,15 @@ class Encoder(nn.Module):
             self._blocks_folded(ws, w, stage_hook)
         else:
             for i, blk in enumerate(self.blocks):
-                blk.fused(ws, w, f"b{i}.")
+                if i == len(self.blocks) - 1 and self.cls_only_last_block and not ws.fp32:
+                    B, N, D = ws.x.shape
+                    p, H = f"b{i}.", ws.qkv.shape[2]
+                    x2 = ws.x.view(B * N, D)
+                    ops.layernorm(x2, w[p + "norm1.w"], w[p + "norm1.b"], _eps_of(blk.norm1), ws.y)
+                    ops.qkv_proj(ws.y, w[p + "qkv.w"], w[p + "qkv.b"], ws.qkv, B, N, H, D // H)
+                    self._last_block_cls_rows(ws, w, p, blk)
+                else:
+                    blk.fused(ws, w, f"b{i}.")
                 if i == 0 and stage_hook is not None:
                     stage_hook("block0", ws.x)
         B, N, D = ws.x.shape

@@ -226,7 +226,8 @@ int vitk_attention_lse(const void* q, const void* k, const void* v, void* ctx, f
  * (bf16 [batch, heads, ntok, hd]), the forward's ctx and lse, and dctx (bf16 [batch, ntok, heads*hd]) to
  * dqkv bf16 [batch, ntok, 3, heads, hd] = the gradient of the fused projection's output as a [rows, 3 D] matrix.
  * dbuf: caller's scratch, f32 [batch, heads, ntok] (rowsum(dctx * ctx) per query: written and read above 288 tokens,
- * where the gradient takes two kernels; untouched below, where one kernel keeps it in LDS).  hd = 64, ntok <= 608. */
+ * where the gradient takes two kernels; untouched below, where one kernel keeps it in LDS).  hd = 64 with ntok <= 608,
+ * or hd = 80 / 96 with ntok <= 288 (always the two kernels). */
 int vitk_attention_backward(const void* q, const void* k, const void* v, const void* ctx, const void* dctx,
                             const float* lse, float* dbuf, void* dqkv, int batch, int heads, int ntok, int hd,
                             float scale, void* stream);

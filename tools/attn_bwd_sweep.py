@@ -1,6 +1,9 @@
 """Time the attention backward (vitk_attention_backward: the dQ pass and the dK/dV pass) on the training shapes.
 
-    python tools/attn_bwd_sweep.py [B H N ...]
+    python tools/attn_bwd_sweep.py [--hd=64] [--torch] [B H N ...]
+
+--torch also times torch's scaled_dot_product_attention backward on the same tensors (what head sizes without a kernel
+fall back to).
 """
 import os
 import statistics
@@ -29,9 +32,10 @@ def timeit(fn, launches=50, rounds=5):
 
 
 def main():
-    a = [int(v) for v in sys.argv[1:]] or [256, 12, 197, 128, 12, 576, 256, 16, 197]
+    hd = next((int(v.split("=")[1]) for v in sys.argv[1:] if v.startswith("--hd=")), 64)
+    with_torch = "--torch" in sys.argv[1:]
+    a = [int(v) for v in sys.argv[1:] if not v.startswith("--")] or [256, 12, 197, 128, 12, 576, 256, 16, 197]
     for B, H, N in zip(a[0::3], a[1::3], a[2::3]):
-        hd = 64
         g = torch.Generator(device="cuda").manual_seed(1)
         qkv = torch.randn(3, B, H, N, hd, generator=g, device="cuda").to(torch.bfloat16)
         out = torch.empty(B, N, H * hd, dtype=torch.bfloat16, device="cuda")
@@ -40,7 +44,17 @@ def main():
         dctx = torch.randn(B, N, H * hd, generator=g, device="cuda").to(torch.bfloat16)
         t = timeit(lambda: ops.attention_backward(qkv, out, dctx, lse, scale))
         fl = 7 * 2.0 * B * H * N * N * hd
-        print(f"B={B} H={H} N={N}: attention backward {t:8.1f} us  {fl / t / 1e6:7.1f} TFLOP/s (7 products)", flush=True)
+        print(f"B={B} H={H} N={N} hd={hd}: attention backward {t:8.1f} us  {fl / t / 1e6:7.1f} TFLOP/s (7 products)", flush=True)
+        if with_torch:
+            q, k, v = (qkv[i].detach().clone().requires_grad_(True) for i in range(3))
+            g4 = dctx.view(B, N, H, hd).transpose(1, 2)
+
+            def torch_bwd():
+                o = torch.nn.functional.scaled_dot_product_attention(q, k, v, scale=scale)
+                torch.autograd.grad(o, (q, k, v), g4)
+
+            tt = timeit(torch_bwd, launches=10, rounds=3)
+            print(f"    torch scaled_dot_product_attention forward + backward {tt:8.1f} us", flush=True)
 
 
 if __name__ == "__main__":

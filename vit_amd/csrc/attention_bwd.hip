@@ -1,6 +1,6 @@
 // Backward of the multi-head self-attention of the ViT blocks (models/transformer.py:42-46) for the
-// training step, head_dim 64, token counts whose K and V (or Q and dO) of one head fit in LDS
-// (gfx950 / CDNA4).
+// training step, head_dim 64 (up to 608 tokens) and 80 / 96 (up to 288 tokens: the two-pass kernels, four waves),
+// i.e. token counts whose K and V (or Q and dO) of one head fit in LDS (gfx950 / CDNA4).
 //
 //   S = scale Q K^T,  P = softmax(S),  O = P V          (forward, attention.hip; it also leaves
 //                                                          L = log2 sum_k exp2(S log2 e) per query row)
@@ -23,10 +23,11 @@
 // from the row-major LDS image through ds_read_b64_tr_b16.  The probabilities are rebuilt as
 // exp2(S log2 e - L): no running maximum, no second softmax pass.
 //
-// LDS rows are 128 B; 16-byte chunk c of row r sits at slot c ^ swz(r), swz(r) = ((r >> 1) & 1) << 2 | ((r >> 2) & 3):
-// conflict-free both for the ds_read_b128 of 16 rows x one chunk column and for the transposed read of
-// 4 rows x 2 chunks.
-// Gradients are written in the layout [batch, ntok, 3, heads, 64]: the [rows, 3 D] matrix the input
+// LDS rows are 128 B (head_dim 64) or 256 B (80 / 96: chunks past the head's last re-read it and are never used);
+// 16-byte chunk c of row r sits at slot c ^ swz(r), swz(r) = ((r >> 1) & 1) << 2 | ((r >> 2) & 3) for 8 slots and
+// (r & 3) << 2 | ((r >> 2) & 3) for 16: conflict-free both for the ds_read_b128 of 16 rows x one chunk column and for
+// the transposed read of 4 rows x 2 chunks.
+// Gradients are written in the layout [batch, ntok, 3, heads, head_dim]: the [rows, 3 D] matrix the input
 // projection's backward GEMMs take.
 #include <type_traits>
 
@@ -39,23 +40,36 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_b;
 typedef __attribute__((address_space(3))) void lds_void_b;
 typedef __attribute__((address_space(1))) const void gbl_void_b;
 
+// Per head_dim: k-steps of 16 columns in the S / dP products, 32-column blocks of the outputs, LDS row bytes.
+template <int HD>
+struct BwdGeom {
+    static_assert(HD == 64 || HD == 80 || HD == 96, "head_dim 64, 80 or 96");
+    static constexpr int KS = (HD + 15) / 16, DB = (HD + 31) / 32, RB = HD == 64 ? 128 : 256;
+    static constexpr int RPP = 1024 / RB;                 // rows per 1 KiB LDS-DMA instruction
+    static constexpr int CPR = RB / 16;                   // 16-byte slots per row
+    __host__ __device__ static constexpr int swz(int row) {
+        return HD == 64 ? ((((row >> 1) & 1) << 2) | ((row >> 2) & 3)) : (((row & 3) << 2) | ((row >> 2) & 3));
+    }
+};
+
 // One owner block (32 queries in MODE 0, 32 keys in MODE 1; the lane's row is orow, its operands t1 / t2) against all
 // resident blocks: accumulates and stores dQ (MODE 0) or dK and dV (MODE 1).  r1 / r2: the resident matrices in LDS
 // (MODE 0: K, V; MODE 1: Q, dO); MODE 0 takes L and D of the lane's query as scalars, MODE 1 reads those of the resident
 // queries from LDS.
-template <int MODE>
+template <int MODE, int HD>
 __device__ __forceinline__ void attn_bwd_owner_block(const char* r1, const char* r2, const float* l_lds, const float* d_lds,
-                                                     const bf16x8 (&t1)[4], const bf16x8 (&t2)[4], float Lc, float Dc,
+                                                     const bf16x8 (&t1)[BwdGeom<HD>::KS], const bf16x8 (&t2)[BwdGeom<HD>::KS], float Lc, float Dc,
                                                      int blocks, int ntok, float c, float scale, int orow, int b, int h,
                                                      int heads, bf16_t* __restrict__ dqkv) {
-    constexpr int HD = 64, KS = 4, DB = 2, RB = 128;
+    using G = BwdGeom<HD>;
+    constexpr int KS = G::KS, DB = G::DB, RB = G::RB;
     const int lane = threadIdx.x & 63;
     const int r = lane & 31, hh = lane >> 5;
     const int tsub = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
     const bool ragged = (ntok & 31) != 0;
-    auto swz = [](int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); };
-    // ---- per-lane LDS offsets inside a resident block of 32 rows (4 KiB); the swizzle of a row depends on its bits
-    // 1..3 only, so none of them changes from block to block and a block costs one add per address
+    auto swz = [](int row) { return G::swz(row); };
+    // ---- per-lane LDS offsets inside a resident block of 32 rows (32 RB bytes); the swizzle of a row depends on its bits
+    // 0..3 only, so none of them changes from block to block and a block costs one add per address
     uint32_t off_row[KS];                  // the lane's row r, chunk 2 ks + hh: the ds_read_b128 of the S / dP products
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) off_row[ks] = (uint32_t)(r * RB + (((ks * 2 + hh) ^ swz(r)) << 4));
@@ -183,6 +197,7 @@ __device__ __forceinline__ void attn_bwd_owner_block(const char* r1, const char*
             for (int d = 0; d < DB; ++d)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
+                    if (d * 32 + 8 * g >= HD) continue;            // head_dim 80: columns 80..95 do not exist
                     u32x2 a = {pack_bf16(out1[d][4 * g], out1[d][4 * g + 1]), pack_bf16(out1[d][4 * g + 2], out1[d][4 * g + 3])};
                     *reinterpret_cast<u32x2*>(base + (MODE == 0 ? 0 : 1) * which_stride + d * 32 + 8 * g) = a;
                     if constexpr (MODE == 1) {
@@ -193,13 +208,14 @@ __device__ __forceinline__ void attn_bwd_owner_block(const char* r1, const char*
         }
 }
 
-template <int MODE, int NW>
+template <int MODE, int NW, int HD>
 __global__ __launch_bounds__(NW * 64) void attention_bwd(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                          const bf16_t* __restrict__ V, const bf16_t* __restrict__ O,
                                                          const bf16_t* __restrict__ dO, const float* __restrict__ LSE,
                                                          float* __restrict__ Dbuf, bf16_t* __restrict__ dqkv, int ntok,
                                                          int heads, float scale) {
-    constexpr int HD = 64, KS = 4, DB = 2, RB = 128;
+    using G = BwdGeom<HD>;
+    constexpr int KS = G::KS, RB = G::RB, RPP = G::RPP, CPR = G::CPR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bh = blockIdx.x;
@@ -211,22 +227,23 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd(const bf16_t* __restric
     float* l_lds = reinterpret_cast<float*>(smem + 2 * npad * RB);      // MODE 1: L and D of every query row
     float* d_lds = l_lds + npad;
 
-    auto swz = [](int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); };
     const size_t head_rows = (size_t)bh * ntok;              // first row of this head in Q / K / V
     const size_t ctx_stride = (size_t)heads * HD;            // row stride of O / dO (heads concatenated)
     const bf16_t* o_head = O + (size_t)b * ntok * ctx_stride + h * HD;
     const bf16_t* do_head = dO + (size_t)b * ntok * ctx_stride + h * HD;
 
-    // ---- stage the two resident matrices: 8 rows per LDS-DMA instruction (1 KiB), rows past ntok re-read the last
+    // ---- stage the two resident matrices: RPP rows per LDS-DMA instruction (1 KiB), rows past ntok re-read the last,
+    // slots past the head's last chunk re-read that chunk
     {
         const bf16_t* s1 = (MODE == 0 ? K : Q) + head_rows * HD;
         const bf16_t* s2 = MODE == 0 ? V + head_rows * HD : do_head;
         const size_t st2 = MODE == 0 ? HD : ctx_stride;
-        const int pieces = npad / 8;
+        const int pieces = npad / RPP;
         for (int pi = wave; pi < 2 * pieces; pi += NW) {      // wave-uniform
             const bool second = pi >= pieces;
-            const int lrow = (second ? pi - pieces : pi) * 8 + (lane >> 3);
-            const int chunk = (lane & 7) ^ swz(lrow);
+            const int lrow = (second ? pi - pieces : pi) * RPP + lane / CPR;
+            int chunk = (lane % CPR) ^ G::swz(lrow);
+            chunk = chunk < HD / 8 ? chunk : HD / 8 - 1;
             const int grow = lrow < ntok ? lrow : ntok - 1;
             const bf16_t* src = second ? s2 + (size_t)grow * st2 + chunk * 8 : s1 + (size_t)grow * HD + chunk * 8;
             __builtin_amdgcn_global_load_lds((gbl_void_b*)src, (lds_void_b*)(smem + pi * 1024), 16, 0, 0);
@@ -270,7 +287,7 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd(const bf16_t* __restric
                 if (hh == 0 && orow < ntok) Dbuf[head_rows + orow] = Dc;
             }
         }
-        attn_bwd_owner_block<MODE>(r1, r2, l_lds, d_lds, t1, t2, Lc, Dc, blocks, ntok, c, scale, orow, b, h, heads, dqkv);
+        attn_bwd_owner_block<MODE, HD>(r1, r2, l_lds, d_lds, t1, t2, Lc, Dc, blocks, ntok, c, scale, orow, b, h, heads, dqkv);
     }
 }
 
@@ -339,7 +356,7 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_fused(const bf16_t* __r
         const float Dc = acc + __shfl_xor(acc, 32, 64);       // the other half-wave holds the other 32 columns
         const float Lc = l_lds[orow];
         if (hh == 0) d_lds[orow] = orow < ntok ? Dc : 0.f;
-        attn_bwd_owner_block<0>(ks_, vs, l_lds, d_lds, t1, t2, Lc, Dc, blocks, ntok, c, scale, orow, b, h, heads, dqkv);
+        attn_bwd_owner_block<0, 64>(ks_, vs, l_lds, d_lds, t1, t2, Lc, Dc, blocks, ntok, c, scale, orow, b, h, heads, dqkv);
     }
     __syncthreads();                                          // D of every query is in LDS
 
@@ -353,7 +370,7 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_fused(const bf16_t* __r
             t1[ks] = *reinterpret_cast<const bf16x8*>(ks_ + orow * RB + (((ks * 2 + hh) ^ sw) << 4));
             t2[ks] = *reinterpret_cast<const bf16x8*>(vs + orow * RB + (((ks * 2 + hh) ^ sw) << 4));
         }
-        attn_bwd_owner_block<1>(qs, dos, l_lds, d_lds, t1, t2, 0.f, 0.f, blocks, ntok, c, scale, orow, b, h, heads, dqkv);
+        attn_bwd_owner_block<1, 64>(qs, dos, l_lds, d_lds, t1, t2, 0.f, 0.f, blocks, ntok, c, scale, orow, b, h, heads, dqkv);
     }
 }
 
@@ -379,16 +396,19 @@ static hipError_t attn_bwd_fused_launch(const void* q, const void* k, const void
     return hipGetLastError();
 }
 
-int attention_bwd_max_tokens() { return 608; }               // two resident [ntok, 64] bf16 matrices + L, D within 160 KiB (155,648 + 4,864 B)
+// two resident [ntok, row bytes] bf16 matrices + L, D within 160 KiB: 608 tokens at 128-byte rows (155,648 + 4,864 B),
+// 288 at 256-byte rows (147,456 + 2,304 B)
+int attention_bwd_max_tokens(int hd) { return hd == 64 ? 608 : (hd == 80 || hd == 96) ? 288 : 0; }
 
-template <int NW>
+template <int NW, int HD>
 static hipError_t attn_bwd_launch(const void* q, const void* k, const void* v, const void* o, const void* d_o,
                                   const float* lse, float* dbuf, void* dqkv, int batch, int heads, int ntok, float scale,
                                   hipStream_t s) {
     const int npad = ((ntok + 31) / 32) * 32;
-    const size_t lds0 = (size_t)2 * npad * 128, lds1 = lds0 + (size_t)2 * npad * 4;
-    auto k0 = &attention_bwd<0, NW>;
-    auto k1 = &attention_bwd<1, NW>;
+    const size_t lds0 = (size_t)2 * npad * BwdGeom<HD>::RB, lds1 = lds0 + (size_t)2 * npad * 4;
+    if (lds1 > 160 * 1024) return hipErrorInvalidValue;
+    auto k0 = &attention_bwd<0, NW, HD>;
+    auto k1 = &attention_bwd<1, NW, HD>;
     if (lds1 > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0);
         if (e != hipSuccess) return e;
@@ -411,7 +431,11 @@ static hipError_t attn_bwd_launch(const void* q, const void* k, const void* v, c
 hipError_t launch_attention_backward(const void* q, const void* k, const void* v, const void* o, const void* d_o,
                                      const float* lse, float* dbuf, void* dqkv, int batch, int heads, int ntok, int hd,
                                      float scale, int variant, hipStream_t s) {
-    if (hd != 64 || ntok < 1 || ntok > attention_bwd_max_tokens()) return hipErrorInvalidValue;
+    if (ntok < 1 || ntok > attention_bwd_max_tokens(hd)) return hipErrorInvalidValue;
+    // head_dim 80 / 96: three 32-column output blocks (two outputs in the dK / dV pass) need the 512 registers of one
+    // wave per SIMD
+    if (hd == 80) return attn_bwd_launch<4, 80>(q, k, v, o, d_o, lse, dbuf, dqkv, batch, heads, ntok, scale, s);
+    if (hd == 96) return attn_bwd_launch<4, 96>(q, k, v, o, d_o, lse, dbuf, dqkv, batch, heads, ntok, scale, s);
     const int tiles = (ntok + 31) / 32;
     const int nw = attention_pick_waves(tiles, 8);
     if (attn_bwd_fits_fused(ntok) && !(variant & 0x200)) {   // attention debug variant bit 9: the two-pass kernels at any size
@@ -424,11 +448,11 @@ hipError_t launch_attention_backward(const void* q, const void* k, const void* v
         }
     }
     switch (nw) {
-        case 4: return attn_bwd_launch<4>(q, k, v, o, d_o, lse, dbuf, dqkv, batch, heads, ntok, scale, s);
-        case 5: return attn_bwd_launch<5>(q, k, v, o, d_o, lse, dbuf, dqkv, batch, heads, ntok, scale, s);
-        case 6: return attn_bwd_launch<6>(q, k, v, o, d_o, lse, dbuf, dqkv, batch, heads, ntok, scale, s);
-        case 7: return attn_bwd_launch<7>(q, k, v, o, d_o, lse, dbuf, dqkv, batch, heads, ntok, scale, s);
-        default: return attn_bwd_launch<8>(q, k, v, o, d_o, lse, dbuf, dqkv, batch, heads, ntok, scale, s);
+        case 4: return attn_bwd_launch<4, 64>(q, k, v, o, d_o, lse, dbuf, dqkv, batch, heads, ntok, scale, s);
+        case 5: return attn_bwd_launch<5, 64>(q, k, v, o, d_o, lse, dbuf, dqkv, batch, heads, ntok, scale, s);
+        case 6: return attn_bwd_launch<6, 64>(q, k, v, o, d_o, lse, dbuf, dqkv, batch, heads, ntok, scale, s);
+        case 7: return attn_bwd_launch<7, 64>(q, k, v, o, d_o, lse, dbuf, dqkv, batch, heads, ntok, scale, s);
+        default: return attn_bwd_launch<8, 64>(q, k, v, o, d_o, lse, dbuf, dqkv, batch, heads, ntok, scale, s);
     }
 }
 

@@ -338,9 +338,11 @@ int vitk_attention_backward(const void* q, const void* k, const void* v, const v
     if (batch <= 0 || heads <= 0 || ntok <= 0) return fail(VITK_ERR_INVALID, "vitk_attention_backward: non-positive size");
     if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(ctx) || !aligned16(dctx) || !aligned16(dqkv))
         return fail(VITK_ERR_INVALID, "vitk_attention_backward: pointers must be 16-byte aligned");
-    if (hd != 64) return fail(VITK_ERR_UNSUPPORTED, "vitk_attention_backward: hd=%d (64 is implemented)", hd);
-    if (ntok > attention_bwd_max_tokens())
-        return fail(VITK_ERR_UNSUPPORTED, "vitk_attention_backward: ntok=%d exceeds the limit %d", ntok, attention_bwd_max_tokens());
+    if (hd != 64 && hd != 80 && hd != 96)
+        return fail(VITK_ERR_UNSUPPORTED, "vitk_attention_backward: hd=%d (64, 80 and 96 are implemented)", hd);
+    if (ntok > attention_bwd_max_tokens(hd))
+        return fail(VITK_ERR_UNSUPPORTED, "vitk_attention_backward: ntok=%d exceeds the limit %d at hd=%d", ntok,
+                    attention_bwd_max_tokens(hd), hd);
     return launched(launch_attention_backward(q, k, v, ctx, dctx, lse, dbuf, dqkv, batch, heads, ntok, hd, scale,
                                               g_attn_variant, reinterpret_cast<hipStream_t>(stream)),
                     "vitk_attention_backward");

@@ -80,7 +80,7 @@ int attention_max_tokens(int hd);
 hipError_t launch_attention(const void* q, const void* k, const void* v, void* out, int batch, int heads,
                             int ntok, int hd, float scale, int variant, hipStream_t s, float* lse = nullptr, int qrows = 0);
 
-int attention_bwd_max_tokens();
+int attention_bwd_max_tokens(int hd);
 hipError_t launch_attention_backward(const void* q, const void* k, const void* v, const void* o, const void* d_o,
                                      const float* lse, float* dbuf, void* dqkv, int batch, int heads, int ntok, int hd,
                                      float scale, int variant, hipStream_t s);

@@ -481,7 +481,7 @@ def attention_lse(qkv, ctx, scale):
 
 
 def attention_backward_supported(N, hd):
-    return hd == 64 and N <= 608
+    return (hd == 64 and N <= 608) or (hd in (80, 96) and N <= 288)
 
 
 def attention_backward(qkv, ctx, dctx, lse, scale):

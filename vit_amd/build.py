@@ -69,5 +69,66 @@ def build(force=False, verbose=True, probes=False):
     return lib
 
 
+# Sources whose kernels wait for inline-asm LDS reads with counted `s_waitcnt lgkmcnt(n)`: the counts hold only while
+# nothing else of the wave is outstanding on that counter.  LDS returns in order, scalar memory does not, so one scalar
+# load (a kernel-argument or descriptor reload) between a transposed LDS read and the wait that covers it could let
+# the wait pass early.
+COUNTED_WAIT_SOURCES = ["attention.hip", "gemm_tn.hip"]
+
+
+def scan_counted_waits(asm_text):
+    """(kernel, line number, instruction) of every scalar-memory instruction that sits, in program text order, between
+    a ds_read_b64_tr_b16 and the next `s_waitcnt` with lgkmcnt(0) of the same kernel."""
+    import re
+    found, kernel, pending = [], None, False
+    for ln, line in enumerate(asm_text.splitlines(), 1):
+        t = line.strip()
+        if re.match(r"^_Z\w+:", t):
+            kernel, pending = t[:-1], False
+            continue
+        if not t or t[0] in ";.":
+            continue
+        ins = t.split()[0]
+        if ins == "ds_read_b64_tr_b16":
+            pending = True
+        elif ins == "s_waitcnt":
+            m = re.search(r"lgkmcnt\((\d+)\)", t)
+            if m and int(m.group(1)) == 0:
+                pending = False
+        elif pending and ins.startswith(("s_load_", "s_buffer_load_", "s_memtime", "s_memrealtime", "s_dcache")):
+            found.append((kernel, ln, t))
+    return found
+
+
+def check_counted_waits(verbose=True):
+    """Compile COUNTED_WAIT_SOURCES to gfx950 assembly (cached beside the objects) and fail if the compiler put a
+    scalar-memory instruction inside a counted-wait region."""
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = _hipcc()
+
+    def asm_of(src):
+        s, out = os.path.join(CSRC, src), os.path.join(objdir, src.replace(".hip", ".s"))
+        if _stale(out, [s] + HEADERS):
+            cmd = [hipcc] + FLAGS + ["-S", "--cuda-device-only", s, "-o", out]
+            if verbose:
+                print("[vit_amd.build]", " ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+        return out
+
+    with ThreadPoolExecutor(max_workers=len(COUNTED_WAIT_SOURCES)) as ex:
+        outs = list(ex.map(asm_of, COUNTED_WAIT_SOURCES))
+    for src, out in zip(COUNTED_WAIT_SOURCES, outs):
+        with open(out) as f:
+            bad = scan_counted_waits(f.read())
+        if bad:
+            k, ln, ins = bad[0]
+            raise RuntimeError(f"{src}: {len(bad)} scalar-memory instruction(s) inside a counted lgkmcnt wait region, "
+                               f"first in {k} at {os.path.basename(out)}:{ln}: {ins}")
+    return True
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, probes="--probes" in sys.argv))
+    if "--check-waits" in sys.argv:
+        print("counted waits clean:", check_counted_waits())

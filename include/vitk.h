@@ -295,6 +295,19 @@ int vitk_gemm_bias_residual_strided(const void* A, int64_t lda, const void* W, c
 int vitk_gemm_bias_residual_ln(const void* A, const void* W, const float* bias, const float* resid, float* out,
                                void* out_bf16, float* stats, int M, int N, int K, void* stream);
 
+/* The same producer with the residual stream x kept as two 16-bit planes instead of f32 plus the bf16 copy (the
+ * stream between the blocks of Encoder.forward, models/transformer.py:95-97; 4 bytes per element written per
+ * residual GEMM instead of 6): plane_h[m][n] = upper half of (bits(x) + 0x8000), i.e. bf16(x) rounded half up, the
+ * operand of the projection that follows as it lies; plane_l[m][n] = lower half of bits(x);
+ * bits(x) = (plane_h << 16) + sext16(plane_l) restores the f32 value exactly.  Three forms, chosen by the pointers:
+ *   resid_f32 != NULL:                 x read as f32, x + A W^T + bias written to the planes, statistics to stats
+ *   resid_f32 == NULL, out_f32 == NULL: planes read and rewritten in place, statistics to stats
+ *   out_f32 != NULL:                   planes read, x + A W^T + bias written as f32 (stats must be NULL)
+ * The sums are formed in the order of vitk_gemm_bias_residual, so the stream's values are bit-identical to the f32
+ * form's.  Same shape limits as vitk_gemm_bias_residual_ln. */
+int vitk_gemm_bias_residual_planes(const void* A, const void* W, const float* bias, const float* resid_f32, void* plane_h,
+                                   void* plane_l, float* out_f32, float* stats, int M, int N, int K, void* stream);
+
 /* ab f32 [rows, 2] = (rstd, -mean * rstd) of every row from the strip statistics over D columns (strips added in
  * index order; biased variance, eps inside the root as nn.LayerNorm has it, models/transformer.py:56,60). */
 int vitk_ln_finalize(const float* stats, float* ab, int rows, int D, float eps, void* stream);

@@ -353,6 +353,59 @@ def test_patch_matrix_embedding_under_the_two_height_plan():
 
 
 # ----------------------------------------------------------------------------- LayerNorm folded into the GEMMs around it
+@pytest.mark.parametrize("M,D,K0", [(50432, 768, 768), (1000, 768, 3072), (197 * 5 + 3, 1024, 1024), (128, 256, 128)])
+def test_residual_stream_as_two_16_bit_planes(M, D, K0):
+    """vitk_gemm_bias_residual_planes: the residual GEMM of a block (models/transformer.py:68-76) with x kept as
+    plane H = bf16(x) rounded half up and plane L = the lower half of x's bits.  All three forms (f32 in / planes out,
+    planes in place, planes in / f32 out) against the f32-stream kernels on the same inputs: the stream's values bit
+    for bit, the statistics bit for bit, plane H equal to the round-to-nearest bf16 copy except on exact ties."""
+    g = torch.Generator(device=DEV).manual_seed(M + D + K0)
+    a1 = torch.randn(M, K0, generator=g, device=DEV).to(torch.bfloat16)
+    a2 = torch.randn(M, K0, generator=g, device=DEV).to(torch.bfloat16)
+    a3 = torch.randn(M, K0, generator=g, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(D, K0, generator=g, device=DEV) * 0.03).to(torch.bfloat16)
+    b = torch.randn(D, generator=g, device=DEV) * 0.1
+    x0 = torch.randn(M, D, generator=g, device=DEV) * 1.5 + 0.4 * torch.randn(M, 1, generator=g, device=DEV)
+    x0[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 1.00390625, 1.01171875, 3.0e-39, -65280.0], device=DEV)   # zeros, ties, a denormal
+    x0[0, 8:10] = torch.tensor([0x3FFFFFFF, -0x40000001], dtype=torch.int32, device=DEV).view(torch.float32)   # the bump carries through plane H
+    # the helpers agree with each other on any bit pattern
+    hh, ll = ops.f32_to_planes(x0)
+    assert torch.equal(ops.planes_to_f32(hh, ll), x0)
+
+    # reference: the f32 stream through the statistics epilogue three times
+    xr = x0.clone()
+    yr = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    sr = torch.empty(M, D // 64, 2, device=DEV)
+    want = []
+    for a in (a1, a2, a3):
+        ops.gemm_bias_residual_ln(a, w, b, xr, xr, yr, sr)
+        want.append((xr.clone(), yr.clone(), sr.clone()))
+
+    ph = torch.full((M, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    pl = torch.full((M, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    st = torch.full((M, D // 64, 2), float("nan"), device=DEV)
+    x_in = x0.clone()
+    ops.gemm_bias_residual_planes(a1, w, b, ph, pl, st, x_in=x_in)                 # f32 in, planes out
+    assert torch.equal(x_in, x0)                                                   # the f32 input is left alone
+    for step, a in ((0, None), (1, a2)):
+        if a is not None:
+            ops.gemm_bias_residual_planes(a, w, b, ph, pl, st)                     # planes in place
+        wx, wy, ws_ = want[step]
+        assert torch.equal(ops.planes_to_f32(ph, pl), wx), step
+        assert torch.equal(st, ws_), step
+        hw, _ = ops.f32_to_planes(wx)
+        assert torch.equal(ph.view(torch.int16), hw.view(torch.int16)), step
+        differs = ph.view(torch.int16) != wy.view(torch.int16)                    # round half up vs half to even: exact ties only
+        assert bool(((wx.view(torch.int32) & 0xFFFF) == 0x8000)[differs].all()) and int(differs.sum()) <= max(4, M * D // 20000)
+    out = torch.full((M, D), float("nan"), device=DEV)
+    ph_before, pl_before = ph.clone(), pl.clone()
+    ops.gemm_bias_residual_planes(a3, w, b, ph, pl, x_out=out)                     # planes in, f32 out
+    assert torch.equal(out, want[2][0])
+    assert torch.equal(ph.view(torch.int16), ph_before.view(torch.int16)) and torch.equal(pl.view(torch.int16), pl_before.view(torch.int16))
+    with pytest.raises(lib.VitkError):
+        ops.gemm_bias_residual_planes(a3, w, b, ph, pl, st, x_out=out)             # statistics go with planes written
+
+
 @pytest.mark.parametrize("M,D,N2,K0", [(50432, 768, 3072, 768), (2000, 768, 2304, 3072), (788, 1024, 4096, 1024),
                                        (131, 256, 768, 256), (50432 + 77, 768, 2304, 768), (5000, 1280, 5120, 1280)])
 def test_layernorm_folded_into_the_gemms_either_side(M, D, N2, K0):

@@ -263,6 +263,9 @@ hipError_t launch_gemm_tiled(const GemmArgs& a, int epilogue, bool gather, int v
             if (variant != 5 && gemm_pp_supports(a, false)) return launch_gemm_pp(a, epilogue, s);
             return launch_gemm_pipe(a, epilogue, false, s);
         case EPI_RESID_LN_F32:
+        case EPI_RESID_LN_FP:
+        case EPI_RESID_LN_PP:
+        case EPI_RESID_PF:
         case EPI_LN_GELU_BF16:
         case EPI_LN_QKV_BF16:              // the two-group persistent kernel only
             if ((size_t)(a.M + 256) * a.N * 4 >= (1ull << 32) || (size_t)a.M * a.lda * 2 >= (1ull << 32) ||

@@ -51,7 +51,9 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
     constexpr bool AUXMUL = (EPI == EPI_MUL_DGELU_BF16 || EPI == EPI_MUL_DTANH_BF16);   // out = bf16(acc) * f'(aux)
     constexpr bool LNIN = (EPI == EPI_LN_GELU_BF16 || EPI == EPI_LN_QKV_BF16);      // LayerNorm applied to the accumulators
     constexpr bool QKV = (EPI == EPI_QKV_BF16 || EPI == EPI_LN_QKV_BF16);
-    constexpr bool LNOUT = EPI == EPI_RESID_LN_F32;                                 // row statistics + bf16 copy of the new rows
+    constexpr bool PIN = (EPI == EPI_RESID_LN_PP || EPI == EPI_RESID_PF);           // residual stream read as two 16-bit planes
+    constexpr bool POUT = (EPI == EPI_RESID_LN_FP || EPI == EPI_RESID_LN_PP);       // ... and written as such
+    constexpr bool LNOUT = (EPI == EPI_RESID_LN_F32 || POUT);                       // row statistics + bf16 copy of the new rows
     constexpr bool OUT_BF16 = (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_BIAS_TANH_BF16 ||
                                QKV || EPI == EPI_BIAS_GELU_DUAL_BF16 || AUXMUL || LNIN);
     constexpr bool DUAL = EPI == EPI_BIAS_GELU_DUAL_BF16;       // two trips through the window: pre-activation, then GELU
@@ -208,7 +210,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
         const int ncol = nw + cc * 4;
         f32x4 bias_rb = {0.f, 0.f, 0.f, 0.f};       // bias in read-back layout: added after the transpose
         if (p.bias) bias_rb = *reinterpret_cast<const f32x4*>(p.bias + ncol);
-        constexpr bool ADDEND = (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_PATCH_F32 || LNOUT);
+        constexpr bool ADDEND = (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_PATCH_F32 || LNOUT || PIN);
         constexpr int QB = (EPI == EPI_PATCH_F32) ? 1 : 2;     // m-tiles per addend batch (register budget)
         // 32-bit byte offsets from the (uniform) tensor bases keep the address registers few; the
         // launcher guarantees that every tensor touched here is smaller than 4 GiB.
@@ -239,6 +241,12 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
                         orw[q][i] = (uint32_t)(rb * p.ntok + 1 + rt);
                         ad[q][i] = *reinterpret_cast<const f32x4*>(pos_b + ((uint32_t)(1 + rt) * p.N + ncol) * 4u);
                         advance_row(rb, rt, 4, p.npatch);
+                    } else if constexpr (PIN) {
+                        // four elements of plane H and of plane L, kept as they are until the batch is used
+                        const uint32_t off = ((uint32_t)m * p.ldo + ncol) * 2u;
+                        const u32x2 hp = *reinterpret_cast<const u32x2*>(reinterpret_cast<const char*>(p.aux) + off);
+                        const u32x2 lp = *reinterpret_cast<const u32x2*>(resid_b + off);
+                        ad[q][i] = __builtin_bit_cast(f32x4, u32x4{hp[0], hp[1], lp[0], lp[1]});
                     } else if constexpr (EPI == EPI_BIAS_RESID_F32 || LNOUT) {
                         ad[q][i] = *reinterpret_cast<const f32x4*>(resid_b + ((uint32_t)m * p.ldo + ncol) * 4u);
                     }
@@ -269,11 +277,33 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
                     const int r = i * 4 + rc;
                     f32x4 v = *reinterpret_cast<const f32x4*>(win + r * 256 + ((cc ^ r) << 4));
                     v = v + bias_rb;
-                    if constexpr (ADDEND) v = v + ad[q][i];
+                    if constexpr (PIN) {
+                        // bits(x) = (H << 16) + sext16(L): H is rounded half up, so L's top bit says whether H was bumped
+                        const u32x4 raw = __builtin_bit_cast(u32x4, ad[q][i]);
+                        const u32x4 xb = {(raw[0] << 16) + (uint32_t)((int32_t)(raw[2] << 16) >> 16),
+                                          (raw[0] & 0xFFFF0000u) + (uint32_t)((int32_t)raw[2] >> 16),
+                                          (raw[1] << 16) + (uint32_t)((int32_t)(raw[3] << 16) >> 16),
+                                          (raw[1] & 0xFFFF0000u) + (uint32_t)((int32_t)raw[3] >> 16)};
+                        v = v + __builtin_bit_cast(f32x4, xb);
+                    } else if constexpr (ADDEND) {
+                        v = v + ad[q][i];
+                    }
                     const int lr = mt * 16 + r;
                     const uint32_t orow_i = (EPI == EPI_PATCH_F32) ? orw[q][i] : (uint32_t)(mw + lr);
-                    if (!MASKED || lr < row_limit)
-                        *reinterpret_cast<f32x4*>(out_b + (orow_i * p.ldo + ncol) * 4u) = v;
+                    if constexpr (POUT) {
+                        const u32x4 vb = __builtin_bit_cast(u32x4, v);
+                        const u32x2 hpk = {((vb[0] + 0x8000u) >> 16) | ((vb[1] + 0x8000u) & 0xFFFF0000u),
+                                           ((vb[2] + 0x8000u) >> 16) | ((vb[3] + 0x8000u) & 0xFFFF0000u)};
+                        const u32x2 lpk = {(vb[0] & 0xFFFFu) | (vb[1] << 16), (vb[2] & 0xFFFFu) | (vb[3] << 16)};
+                        if (!MASKED || lr < row_limit) {
+                            const uint32_t off = (orow_i * p.ldo + ncol) * 2u;
+                            *reinterpret_cast<u32x2*>(out_b + off) = lpk;
+                            *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(p.out2) + off) = hpk;
+                        }
+                    } else {
+                        if (!MASKED || lr < row_limit)
+                            *reinterpret_cast<f32x4*>(out_b + (orow_i * p.ldo + ncol) * 4u) = v;
+                    }
                     if constexpr (LNOUT) {
                         // the new row's bf16 copy (the next GEMM's operand) and this strip's share of its LayerNorm
                         // statistics: 16 lanes hold the row's 64 columns of this wave
@@ -282,8 +312,10 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4 (&a
                         const float ps = row16_sum(s2[0] + s2[1]);
                         const float pq = row16_sum(q2[0] + q2[1]);
                         if (!MASKED || lr < row_limit) {
-                            const u32x2 pk = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-                            *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(p.out2) + (orow_i * p.ldo + ncol) * 2u) = pk;
+                            if constexpr (!POUT) {
+                                const u32x2 pk = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                                *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(p.out2) + (orow_i * p.ldo + ncol) * 2u) = pk;
+                            }
                             if (cc == 0)     // 32-bit offsets: the launcher keeps every tensor below 4 GiB
                                 *reinterpret_cast<f32x2*>(reinterpret_cast<char*>(p.ln_stats) +
                                                           (orow_i * (uint32_t)(p.N >> 6) + (uint32_t)(nw >> 6)) * 8u) = f32x2{ps, pq};

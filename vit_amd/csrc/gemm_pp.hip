@@ -429,6 +429,9 @@ hipError_t launch_gemm_pp(const GemmArgs& a, int epilogue, hipStream_t s) {
         case EPI_RESID_LN_F32: return launch_pp<EPI_RESID_LN_F32>(a, s);
         case EPI_LN_GELU_BF16: return launch_pp<EPI_LN_GELU_BF16>(a, s);
         case EPI_LN_QKV_BF16: return launch_pp<EPI_LN_QKV_BF16>(a, s);
+        case EPI_RESID_LN_FP: return launch_pp<EPI_RESID_LN_FP>(a, s);
+        case EPI_RESID_LN_PP: return launch_pp<EPI_RESID_LN_PP>(a, s);
+        case EPI_RESID_PF: return launch_pp<EPI_RESID_PF>(a, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -70,7 +70,7 @@ int dense(const char* name, const void* A, const void* W, const float* bias, con
 
 extern "C" {
 
-int vitk_version(void) { return 9; }
+int vitk_version(void) { return 10; }
 
 const char* vitk_last_error(void) { return g_err; }
 
@@ -225,6 +225,39 @@ int vitk_gemm_bias_residual_ln(const void* A, const void* W, const float* bias, 
     a.M = M; a.N = N; a.K = K; a.lda = K; a.ldo = N;
     a.order = g_gemm_variant >> 4;
     hipError_t e = launch_gemm_tiled(a, EPI_RESID_LN_F32, false, 0, reinterpret_cast<hipStream_t>(stream));
+    if (e == hipErrorInvalidValue) return fail(VITK_ERR_UNSUPPORTED, "%s: a tensor of 4 GiB or more", name);
+    return launched(e, name);
+}
+
+int vitk_gemm_bias_residual_planes(const void* A, const void* W, const float* bias, const float* resid_f32, void* plane_h,
+                                   void* plane_l, float* out_f32, float* stats, int M, int N, int K, void* stream) {
+    const char* name = "vitk_gemm_bias_residual_planes";
+    if (!A || !W || !plane_h || !plane_l) return fail(VITK_ERR_INVALID, "%s: null pointer", name);
+    if (resid_f32 && out_f32) return fail(VITK_ERR_INVALID, "%s: f32 stream in and out (use vitk_gemm_bias_residual_ln)", name);
+    if ((out_f32 != nullptr) == (stats != nullptr))
+        return fail(VITK_ERR_INVALID, "%s: statistics go with the planes written, none with the f32 stream written", name);
+    if (M <= 0 || N <= 0 || K <= 0) return fail(VITK_ERR_INVALID, "%s: non-positive size %dx%dx%d", name, M, N, K);
+    if (!aligned16(A) || !aligned16(W) || !aligned16(plane_h) || !aligned16(plane_l) || (bias && !aligned16(bias)) ||
+        (resid_f32 && !aligned16(resid_f32)) || (out_f32 && !aligned16(out_f32)) || (stats && !aligned16(stats)))
+        return fail(VITK_ERR_INVALID, "%s: pointers must be 16-byte aligned", name);
+    if (!ln_fold_shape_ok(M, N, K))
+        return fail(VITK_ERR_UNSUPPORTED, "%s: M=%d N=%d K=%d (M >= 128, N a multiple of 256, K of 128)", name, M, N, K);
+    GemmArgs a = {};
+    a.A = A; a.W = W; a.bias = bias; a.ln_stats = stats;
+    a.M = M; a.N = N; a.K = K; a.lda = K; a.ldo = N;
+    a.order = g_gemm_variant >> 4;
+    int epi;
+    if (resid_f32) {                 // f32 stream in, planes out
+        epi = EPI_RESID_LN_FP;
+        a.resid = resid_f32; a.out = plane_l; a.out2 = plane_h;
+    } else if (!out_f32) {           // planes in, planes out (in place)
+        epi = EPI_RESID_LN_PP;
+        a.resid = reinterpret_cast<const float*>(plane_l); a.aux = plane_h; a.out = plane_l; a.out2 = plane_h;
+    } else {                         // planes in, f32 stream out
+        epi = EPI_RESID_PF;
+        a.resid = reinterpret_cast<const float*>(plane_l); a.aux = plane_h; a.out = out_f32;
+    }
+    hipError_t e = launch_gemm_tiled(a, epi, false, 0, reinterpret_cast<hipStream_t>(stream));
     if (e == hipErrorInvalidValue) return fail(VITK_ERR_UNSUPPORTED, "%s: a tensor of 4 GiB or more", name);
     return launched(e, name);
 }

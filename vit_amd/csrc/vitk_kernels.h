@@ -23,6 +23,12 @@ enum Epilogue {
     EPI_RESID_LN_F32 = 10,   // out f32 [M,N] = resid + acc + bias; out2 bf16 [M,N]; ln_stats f32 [M, N/64, 2]
     EPI_LN_GELU_BF16 = 11,   // out bf16 [M,N] = gelu(ln_ab[m][0] acc + ln_ab[m][1] ln_s[n] + bias[n])
     EPI_LN_QKV_BF16 = 12,    // the same value scattered head-major as EPI_QKV_BF16
+    // The producer with the residual stream kept as two 16-bit planes instead of f32 plus a bf16 copy: plane H = the upper
+    // half of (bits(x) + 0x8000), i.e. bf16(x) rounded half up, a GEMM operand as it lies; plane L = the lower half of
+    // bits(x); bits(x) = (H << 16) + sext16(L) restores the f32 value exactly.  4 bytes per element written instead of 6.
+    EPI_RESID_LN_FP = 13,    // resid f32 in; out = plane L, out2 = plane H of resid + acc + bias; ln_stats as above
+    EPI_RESID_LN_PP = 14,    // planes in (aux = H, resid = L; may alias out2 / out), planes out, ln_stats
+    EPI_RESID_PF = 15,       // planes in (aux = H, resid = L), out f32 [M,N] = x + acc + bias; no statistics
 };
 
 // epilogues of the fp32-mode GEMM (f32path.hip)
@@ -34,9 +40,10 @@ struct GemmArgs {
     const float* bias;   // [N] or nullptr
     void* out;
     void* out2;          // EPI_BIAS_GELU_DUAL_BF16: the pre-activation
-    const float* resid;  // EPI_BIAS_RESID_F32 (may alias out)
+    const float* resid;  // EPI_BIAS_RESID_F32 (may alias out); EPI_RESID_LN_PP / EPI_RESID_PF: plane L, 16-bit [M,N]
     const float* pos;    // EPI_PATCH_F32: pos_embed [Ntok,N]
-    const void* aux;     // EPI_MUL_*: bf16 [M,N] (row stride ldo), what the activation's derivative is taken of
+    const void* aux;     // EPI_MUL_*: bf16 [M,N] (row stride ldo), what the activation's derivative is taken of;
+                         // EPI_RESID_LN_PP / EPI_RESID_PF: plane H
     float* ln_stats;     // EPI_RESID_LN_F32: f32 [M, N/64, 2]
     const float* ln_ab;  // EPI_LN_*: f32 [M, 2] = (rstd, -mean * rstd) of every row of x
     const float* ln_s;   // EPI_LN_*: f32 [N] column sums of the gamma-scaled bf16 weight

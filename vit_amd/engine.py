@@ -149,6 +149,7 @@ class Workspace:
         # LayerNorm folded into the GEMMs either side of it: strip statistics and per-row factors
         self.ln_stats = None if fp32 else e(B * N, max(D // 64, 1), 2, dtype=f32)
         self.ln_ab = None if fp32 else e(B * N, 2, dtype=f32)
+        self.xl = None if fp32 else e(B * N, D, dtype=bf)    # plane L of the residual stream while it lives as two 16-bit planes (plane H is y)
         self.img16 = None
         self.cols = None
 

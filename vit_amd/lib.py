@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VITK_LIB") or os.path.join(_HERE, "libvitk.so")
 
 VITK_F32, VITK_BF16 = 0, 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int
@@ -51,6 +51,7 @@ SIGNATURES = {
     "vitk_attention_rows": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p],
     "vitk_gemm_bias_residual_strided": [_p, _i64, _p, _p, _p, _p, _i64, _i, _i, _i, _p],
     "vitk_gemm_bias_residual_ln": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "vitk_gemm_bias_residual_planes": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "vitk_ln_finalize": [_p, _p, _i, _i, _f, _p],
     "vitk_gemm_ln_bias_gelu": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "vitk_qkv_proj_ln": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],

@@ -210,6 +210,49 @@ def gemm_bias_residual_ln(a, w, bias, resid, out, out16, stats):
     return out
 
 
+def gemm_bias_residual_planes(a, w, bias, plane_h, plane_l, stats=None, x_in=None, x_out=None):
+    """The residual GEMM x' = x + a @ w.T + bias with the stream x held as two 16-bit planes (plane_h = bf16(x) rounded
+    half up, plane_l = the lower half of x's f32 bit pattern; see planes_to_f32).  x_in (f32): read x from it and write
+    the planes; x_out (f32): read the planes and write x' there; neither: planes in place.  stats f32 [M, N/64, 2]
+    receives the new rows' strip statistics whenever the planes are written."""
+    L = _lib.load()
+    _chk(a, torch.bfloat16, "A"); _chk(w, torch.bfloat16, "W"); _chk(bias, torch.float32, "bias")
+    _chk(plane_h, torch.bfloat16, "plane_h"); _chk(plane_l, torch.bfloat16, "plane_l")
+    M, N, K = _dense_shapes(a, w, plane_h, "gemm_bias_residual_planes")
+    if tuple(plane_l.shape) != (M, N):
+        raise _lib.VitkError(f"gemm_bias_residual_planes: plane_l {tuple(plane_l.shape)} vs [{M},{N}]")
+    for t, n in ((x_in, "x_in"), (x_out, "x_out")):
+        if t is not None:
+            _chk(t, torch.float32, n)
+            if tuple(t.shape) != (M, N):
+                raise _lib.VitkError(f"gemm_bias_residual_planes: {n} {tuple(t.shape)} vs [{M},{N}]")
+    if stats is not None:
+        _chk(stats, torch.float32, "stats")
+        if stats.numel() != M * (N // 64) * 2:
+            raise _lib.VitkError(f"gemm_bias_residual_planes: stats {tuple(stats.shape)} vs [{M},{N // 64},2]")
+    with _span("gemm_bias_residual"):
+        _lib.check(L.vitk_gemm_bias_residual_planes(_ptr(a), _ptr(w), _ptr(bias), _ptr(x_in) if x_in is not None else None,
+                                                    _ptr(plane_h), _ptr(plane_l), _ptr(x_out) if x_out is not None else None,
+                                                    _ptr(stats) if stats is not None else None, M, N, K, _stream()), L)
+    return x_out if x_out is not None else plane_h
+
+
+def planes_to_f32(plane_h, plane_l):
+    """The f32 tensor two 16-bit planes stand for: bits(x) = (plane_h << 16) + sext16(plane_l), exactly."""
+    h = plane_h.view(torch.int16).to(torch.int32)
+    lo = plane_l.view(torch.int16).to(torch.int32)
+    return ((h << 16) + lo).view(torch.float32)
+
+
+def f32_to_planes(x):
+    """(plane_h, plane_l) of an f32 tensor: plane_h = upper half of bits(x) + 0x8000 (bf16 rounded half up), plane_l =
+    lower half of bits(x).  torch ops; the GEMM epilogues write the same."""
+    b = x.contiguous().view(torch.int32)
+    h = ((b + 0x8000) >> 16).to(torch.int16).view(torch.bfloat16)
+    lo = (b << 16 >> 16).to(torch.int16).view(torch.bfloat16)
+    return h, lo
+
+
 def ln_finalize(stats, ab, D, eps):
     """ab f32 [rows, 2] = (rstd, -mean * rstd) per row from the strip statistics of a D-column LayerNorm."""
     L = _lib.load()

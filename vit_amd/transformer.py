@@ -123,6 +123,8 @@ class Encoder(nn.Module):
         # the previous block's fc2) and norm2 (statistics from out_proj)
         mode = os.environ.get("VIT_AMD_LN_FOLD_MODE", "both")
         self.fold_norm1, self.fold_norm2 = mode in ("both", "ln1"), mode in ("both", "ln2")
+        # with both folds on: the residual stream between the blocks as two 16-bit planes (see _blocks_folded)
+        self.residual_planes = os.environ.get("VIT_AMD_NO_PLANES", "0") != "1"
         # Inference, bf16 mode: evaluate the last block past its q/k/v projection for the cls token only (exact: the
         # encoder returns token 0, and those ops are per token).  Off by default: the full block is what the
         # reference's forward computes and what the throughput figures count.
@@ -161,6 +163,13 @@ class Encoder(nn.Module):
         hd = D // H
         last = len(self.blocks) - 1
         fold1, fold2 = self.fold_norm1, self.fold_norm2
+        # With both folds on, the stream lives as two 16-bit planes from block 0's out_proj to the last block's: plane H
+        # (ws.y) is bf16(x), the operand of the projection that follows, plane L (ws.xl) the lower half of x's f32 bits.
+        # Every value of x is what the f32 stream would hold (the planes restore it exactly); a residual GEMM writes
+        # 4 bytes per element instead of f32 + the bf16 copy.
+        planes = fold1 and fold2 and last >= 1 and self.residual_planes
+        ctx2 = ws.ctx.view(B * N, D)
+        in_planes = False                    # x is in (ws.y, ws.xl), ws.x is stale
         normed = False                       # ws.y / ws.ln_ab hold bf16(x) and the row factors of the coming norm1
         for i, blk in enumerate(self.blocks):
             p = f"b{i}."
@@ -170,27 +179,41 @@ class Encoder(nn.Module):
                 ops.layernorm(x2, w[p + "norm1.w"], w[p + "norm1.b"], _eps_of(blk.norm1), ws.y)
                 ops.qkv_proj(ws.y, w[p + "qkv.w"], w[p + "qkv.b"], ws.qkv, B, N, H, hd)
             if i == last and self.cls_only_last_block:
+                if in_planes:                # only the cls rows of x are read from here on
+                    ws.x[:, 0].copy_(ops.planes_to_f32(ws.y.view(B, N, D)[:, 0], ws.xl.view(B, N, D)[:, 0]))
                 self._last_block_cls_rows(ws, w, p, blk)
                 if i == 0 and stage_hook is not None:
                     stage_hook("block0", ws.x)
                 break
             ops.attention(ws.qkv, ws.ctx, blk.attention.scaling)
             if fold2 and i < last:       # (the last block keeps its norm2 launch: the cls-only form above shares its kernels)
-                ops.gemm_bias_residual_ln(ws.ctx.view(B * N, D), w[p + "out.w"], w[p + "out.b"], x2, x2, ws.y, ws.ln_stats)
+                if planes:
+                    ops.gemm_bias_residual_planes(ctx2, w[p + "out.w"], w[p + "out.b"], ws.y, ws.xl, ws.ln_stats,
+                                                  x_in=None if in_planes else x2)
+                    in_planes = True
+                else:
+                    ops.gemm_bias_residual_ln(ctx2, w[p + "out.w"], w[p + "out.b"], x2, x2, ws.y, ws.ln_stats)
                 ops.ln_finalize(ws.ln_stats, ws.ln_ab, D, _eps_of(blk.norm2))
                 ops.gemm_ln_bias_gelu(ws.y, w[p + "fc1.wg"], ws.ln_ab, w[p + "fc1.s"], w[p + "fc1.c"], ws.h)
             else:
-                ops.gemm_bias_residual(ws.ctx.view(B * N, D), w[p + "out.w"], w[p + "out.b"], x2, x2)
+                if in_planes:
+                    ops.gemm_bias_residual_planes(ctx2, w[p + "out.w"], w[p + "out.b"], ws.y, ws.xl, x_out=x2)
+                    in_planes = False
+                else:
+                    ops.gemm_bias_residual(ctx2, w[p + "out.w"], w[p + "out.b"], x2, x2)
                 ops.layernorm(x2, w[p + "norm2.w"], w[p + "norm2.b"], _eps_of(blk.norm2), ws.y)
                 ops.gemm_bias_gelu(ws.y, w[p + "fc1.w"], w[p + "fc1.b"], ws.h)
             normed = fold1 and i < last
-            if normed:
+            if normed and in_planes:
+                ops.gemm_bias_residual_planes(ws.h, w[p + "fc2.w"], w[p + "fc2.b"], ws.y, ws.xl, ws.ln_stats)
+                ops.ln_finalize(ws.ln_stats, ws.ln_ab, D, _eps_of(self.blocks[i + 1].norm1))
+            elif normed:
                 ops.gemm_bias_residual_ln(ws.h, w[p + "fc2.w"], w[p + "fc2.b"], x2, x2, ws.y, ws.ln_stats)
                 ops.ln_finalize(ws.ln_stats, ws.ln_ab, D, _eps_of(self.blocks[i + 1].norm1))
             else:
                 ops.gemm_bias_residual(ws.h, w[p + "fc2.w"], w[p + "fc2.b"], x2, x2)
             if i == 0 and stage_hook is not None:
-                stage_hook("block0", ws.x)
+                stage_hook("block0", ops.planes_to_f32(ws.y, ws.xl).view(B, N, D) if in_planes else ws.x)
 
     def fused(self, ws, w, stage_hook=None):
         """All blocks, then the final LayerNorm on the cls row only: LayerNorm is per token

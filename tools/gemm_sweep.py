@@ -42,6 +42,11 @@ def main():
             out16 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
             stats = torch.empty(M, N // 64, 2, device=dev)
             run = lambda: ops.gemm_bias_residual_ln(A, W, b, out, out, out16, stats)   # noqa: E731
+        elif epi == "residplanes":  # the same with the stream as two 16-bit planes, in place
+            ph = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+            pl = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+            stats = torch.empty(M, N // 64, 2, device="cuda")
+            run = lambda: ops.gemm_bias_residual_planes(A, W, b, ph, pl, stats)   # noqa: E731
         elif epi == "lngelu":       # the GELU epilogue with the LayerNorm row factors (here 1 and 0: same values as gelu)
             out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
             ab = torch.zeros(M, 2, device=dev)

@@ -96,6 +96,12 @@ def main():
             flops=2.0 * R * M * D)
         rec("fc2 + residual + LN stats", timeit(lambda: ops.gemm_bias_residual_ln(h, w_fc2, b_d, x, x, y, stats), it),
             flops=2.0 * R * M * D)
+        ph, pl = torch.empty(R, D, dtype=bf, device=dev), torch.empty(R, D, dtype=bf, device=dev)
+        ops.gemm_bias_residual_planes(ctx.view(R, D), w_out, b_d, ph, pl, stats, x_in=x)
+        rec("out_proj + residual planes + LN stats", timeit(lambda: ops.gemm_bias_residual_planes(ctx.view(R, D), w_out, b_d, ph, pl, stats), it),
+            flops=2.0 * R * D * D)
+        rec("fc2 + residual planes + LN stats", timeit(lambda: ops.gemm_bias_residual_planes(h, w_fc2, b_d, ph, pl, stats), it),
+            flops=2.0 * R * M * D)
         rec("qkv_proj (LN folded)", timeit(lambda: ops.qkv_proj_ln(y, w_qkv, ab, cs_q, c_q, qkv, B, N, H, hd), it),
             flops=2.0 * R * 3 * D * D)
     o16 = torch.empty(R, D, dtype=bf, device=dev)

@@ -25,6 +25,8 @@ def short(name):
 # (pp<11> / <12> / <10>: the GELU, q/k/v and residual epilogues with the LayerNorm folded in, what the forward runs)
 TRAFFIC_KERNELS = {"fc1": "gemm_bf16_pp<11, 0>", "fc1_separate_ln": "gemm_bf16_pp<1, 0>", "qkv_proj": "gemm_bf16_pp<12, 0>",
                    "qkv_proj_separate_ln": "gemm_bf16_pp<3, 0>", "residual_ln_stats": "gemm_bf16_pp<10, 0>",
+                   "residual_planes": "gemm_bf16_pp<14, 0>", "residual_f32_to_planes": "gemm_bf16_pp<13, 0>",
+                   "residual_planes_to_f32": "gemm_bf16_pp<15, 0>",
                    "residual": "gemm_bf16_pp<2, 0>", "attention": "attention_fwd<", "layernorm": "layernorm_rows<",
                    "ln_finalize": "ln_finalize_rows"}
 

@@ -2,7 +2,7 @@
 rounds, inside one process (median and min over the rounds are printed), because launch-to-launch
 clock and box-to-box differences are larger than most kernel changes.
 
-    python tools/gemm_sweep.py [--variant=0,4,...] [--epi=bias|resid|gelu] [--rounds=5] [--launches=10] M N K [M N K ...]
+    python tools/gemm_sweep.py [--variant=0,4,...] [--epi=bias|resid|residln|residplanes|residpf|gelu|lngelu] [--rounds=5] [--launches=10] M N K [M N K ...]
 """
 import os
 import statistics
@@ -47,6 +47,11 @@ def main():
             pl = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
             stats = torch.empty(M, N // 64, 2, device="cuda")
             run = lambda: ops.gemm_bias_residual_planes(A, W, b, ph, pl, stats)   # noqa: E731
+        elif epi == "residpf":      # planes in, f32 out, no statistics (the last block's out_proj)
+            ph = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+            pl = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+            out = torch.zeros(M, N, dtype=torch.float32, device=dev)
+            run = lambda: ops.gemm_bias_residual_planes(A, W, b, ph, pl, x_out=out)   # noqa: E731
         elif epi == "lngelu":       # the GELU epilogue with the LayerNorm row factors (here 1 and 0: same values as gelu)
             out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
             ab = torch.zeros(M, 2, device=dev)
